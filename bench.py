@@ -1,6 +1,11 @@
 """GRPO rollout samples/sec on MI355X (BASELINE.json metric) -- one prompt group per GPU per step, weak scaling.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: one rank per GPU over RCCL.  Either the caller starts the ranks (python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or -- when WORLD_SIZE is not set
+-- this process starts them itself as a child `python -m torch.distributed.run` (as the reference launches its trainer,
+/root/reference/train/scripts/train_grpo.sh:41) and only forwards the one JSON line; the parent never touches the GPU.
 
 A "step" = one optimiser step = one pass of the hot path over P prompt groups per rank (default P = 2: the reference's
 per_device_train_batch_size x gradient_accumulation_steps; two groups of G = 8 fill the 16-row MFMA tile of the decode
@@ -49,6 +54,11 @@ def parse():
     p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                    help="fp8: the decode GEMVs stream per-channel e4m3 copies of the LM weights (BASELINE config 5); prefill, "
                         "scoring and training stay bf16; the copies are re-quantised after every optimiser step (timed)")
+    p.add_argument("--launch-check", action="store_true",
+                   help="rehearse the N-rank launch only: process group, barrier, max-over-ranks timing and the JSON line, no "
+                        "engine work (runs without a GPU; tests/test_bench_launch.py)")
+    p.add_argument("--no-recipe-shape", action="store_true",
+                   help="skip the extra untimed steps at ONE prompt group per GPU (the reference recipe's per-device shape)")
     p.add_argument("--prompts-per-gpu", type=int, default=16,
                    help="prompt groups per GPU per optimiser step (the reference's per_device_train_batch_size x "
                         "gradient_accumulation_steps); groups are decoded together, P*G <= 128 rows per weight pass")
@@ -134,19 +144,87 @@ def cpu_baseline(cfg_name, n_frames, G, C):
                       f"decode-step {t_dec_step + t_head:.2f}s scoring {t_score:.1f}s"}
 
 
+def self_launch(a):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a CHILD `python -m torch.distributed.run` (a fresh
+    process tree: this parent has not initialised the GPU and never does), stream its stderr through, forward the ranks' one
+    JSON line on stdout and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print("[bench] the ranks exited without printing a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def launch_check(a, world, rank, backend):
+    """The distributed skeleton of the bench without the engine: barrier, K timed no-op steps, max over ranks, one JSON line."""
+    import torch.distributed as dist
+    dev = "cpu" if backend == "gloo" else f"cuda:{torch.cuda.current_device()}"
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.001 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(got, tt)
+        per_rank = [float(g.item()) for g in got]
+    if rank == 0:
+        print(json.dumps({"metric": "GRPO rollout samples/sec", "value": 0.0, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": max(per_rank) / max(a.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "launch_check": True, "dist_backend": backend if world > 1 else None,
+                          "rccl_ranks": world if backend == "nccl" and world > 1 else 0,
+                          "rank_ms_per_step": [t / max(a.steps, 1) * 1e3 for t in per_rank]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: reporting n_gpus={world}", file=sys.stderr)
+    backend = os.environ.get("VR2_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; gloo only for single-GPU / CPU rehearsals
+    if a.launch_check and (backend == "gloo" or world == 1):
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        return launch_check(a, world, rank, "gloo")
     local = local % max(1, torch.cuda.device_count())       # (rehearsals put several ranks on one GPU; a node has one GPU per rank)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("VR2_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for single-GPU rehearsals
         kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
         dist.init_process_group(backend, **kw)
+    if a.launch_check:
+        return launch_check(a, world, rank, backend)
     from video_r2_amd import lib, weights as W
     from video_r2_amd.engine import Engine
     from video_r2_amd.host import grpo as hg
@@ -169,20 +247,21 @@ def main():
     from video_r2_amd.train import Trainer
     upd = None if a.no_update else Trainer(eng, pol)       # fp32 masters + Adam moments + transposed packed copies
     P = a.prompts_per_gpu
-    n_prompts = (a.steps + a.warmup + 1) * P                # + one instrumented step for the phase split
+    n_prompts = (a.steps + a.warmup + 1) * P + 2            # + one instrumented step for the phase split + 2 recipe-shaped steps
     prompts = [synth_prompt(cfg, a.frames, rank * 1000 + i, device) for i in range(n_prompts)]
     slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="pol")
     torch.cuda.synchronize()
 
-    def step(i, rec=None):
+    def step(i, rec=None, mine=None):
         """One GRPO step over this rank's P prompt groups.  rec(name) marks a phase boundary (instrumented extra step only)."""
         mark = rec if rec is not None else (lambda name: None)
-        mine = prompts[i * P:(i + 1) * P]
+        mine = prompts[i * P:(i + 1) * P] if mine is None else mine
+        Pn = len(mine)
         enc, states = [], []
         for p_, (px, grid, ids) in enumerate(mine):
             mark(None)
             emb, plan = eng.encode_video(px, [grid])
-            emb = emb.clone() if P > 1 else emb                     # the ViT output workspace is reused by the next group
+            emb = emb.clone() if Pn > 1 else emb                     # the ViT output workspace is reused by the next group
             mark("vit")
             enc.append((emb, plan))
             states.append(eng.prefill(pol, ids, emb, plan, [1.0], tag="pol", prefix_out=slots[p_]))
@@ -210,10 +289,10 @@ def main():
             if upd is not None:
                 upd.backward(out["dlogp"])                           # gradients accumulate over the step's prompt groups
             mark("loss+backward")
-            loss += float(out["loss"].item()) / P
+            loss += float(out["loss"].item()) / Pn
         mark(None)
         if upd is not None:
-            upd.optimizer_step(lr=1e-6, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / P)   # + RCCL all-reduce for N>1
+            upd.optimizer_step(lr=1e-6, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / Pn)   # + RCCL all-reduce for N>1
             if fp8:
                 with torch.cuda.stream(eng.stream):
                     W.add_fp8_decode_copies(pol)                     # the next rollout decodes the updated policy
@@ -236,11 +315,30 @@ def main():
         loss = step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    rank_dt = [dt]
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        got = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(got, tt)
+        rank_dt = [float(g.item()) for g in got]
+        dt = max(rank_dt)                                   # the job is as slow as its slowest rank
+
+    # ---- the reference recipe's per-device shape: ONE prompt group per GPU per optimiser step (train_grpo.sh:4-7:
+    # per_device_train_batch_size 1 -> G rows per decode weight pass).  Untimed for `value`; reported beside it.
+    recipe = None
+    if not a.no_recipe_shape and P > 1:
+        step(0, mine=prompts[-2:-1])                           # captures the G-row decode graph
+        barrier()
+        t1 = time.perf_counter()
+        step(0, mine=prompts[-1:])
+        barrier()
+        recipe = time.perf_counter() - t1
+        if world > 1:
+            import torch.distributed as dist
+            tr = torch.tensor([recipe], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            recipe = float(tr.item())
 
     # ---- phase split + roofline of the dominant kernel, HIP events on the engine's stream (rank 0)
     if rank != 0:
@@ -355,6 +453,10 @@ def main():
         samples = G * P * a.steps * world
         line = {
             "metric": "GRPO rollout samples/sec", "value": samples / dt, "unit": "samples/s", "n_gpus": world,
+            "value_is": "completions / wall second of the FULL step (rollout + reference and policy scoring + loss + backward + "
+                        f"all-reduce + AdamW) at {P} prompt groups per GPU per optimiser step; rollout-only rate: rollout_samples_per_s",
+            "rccl_ranks": world if (world > 1 and backend == "nccl") else 0, "dist_backend": backend if world > 1 else None,
+            "rank_ms_per_step": [t / a.steps * 1e3 for t in rank_dt],
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not fp8 else "bf16 (decode weights fp8 e4m3, per-channel scales)", "data": "synthetic",
             "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} {a.frames} frames 224^2, G={G}, {C} new tokens, {P} prompt group(s) per GPU per step",
@@ -367,6 +469,9 @@ def main():
             "last_loss": loss,
             "hbm_peak_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),   # torch allocator high-water mark on rank 0
         }
+        if recipe is not None:
+            line["recipe_shape_samples_per_s"] = G * world / recipe        # 1 group per GPU per step, full step, one sample of it
+            line["recipe_shape_ms_per_step"] = recipe * 1e3
         line.update(extra)
         if roof:
             line["roofline"] = roof

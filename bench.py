@@ -34,9 +34,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_TRAFFIC_128 = 284.0e6  # same, 128 rows (profiles/r01_pmc_gemv_gateup_64rows.md, second table)
-PMC_TRAFFIC_W8_128 = 148.3e6  # fp8 weights, 128 rows (same file, third table)
-PMC_TRAFFIC_64 = 277.8e6  # HBM bytes per gate/up launch at 64 rows (rocprofv3 PMC, profiles/r01_pmc_gemv_gateup_64rows.md)
+PMC_TRAFFIC_W8_128 = 148.3e6  # fp8 weights, 128 rows (profiles/r01_pmc_gemv_gateup_64rows.md, third table)
+# HBM bytes per launch by (projection, rows), rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE): filled from profiles/*.md
+PMC_TRAFFIC = {("gu", 8): 273.2e6}
 
 
 def parse():
@@ -418,13 +418,36 @@ def main():
         if fp8r:
             kname = "gemv16_w8_kernel<1>" if NG <= 16 else ("gemv_lds_w8_kernel<1, %d>" % mbs if NG <= 64 else "gemv_lds_w8s_kernel<1, 8, 1>")
         else:
-            kname = "gemv16_kernel<1, 1, 4>" if NG <= 16 else "gemv_lds_kernel<1, %d, 1>" % mbs
-        # HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), profiles/r01_pmc_gemv_gateup*.md;
-        # measured at the 7B shape for 8, 64 and 128 rows only
-        traffic = {8: 273.2e6, 64: PMC_TRAFFIC_64, 128: PMC_TRAFFIC_128}.get(NG) if (a.model == "7b" and not fp8r) else (PMC_TRAFFIC_W8_128 if (a.model == "7b" and fp8r and NG == 128) else None)
+            kname = "gemv16_kernel<1, 1, 4>" if NG <= 16 else "gemv_ring_kernel<1, %d, 1, 0>" % mbs
+        # HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/r02_pmc_gemv_ring.md
+        # (7B shape, bf16 weights; 8 rows: profiles/r01_pmc_gemv_gateup.md)
+        traffic = PMC_TRAFFIC.get(("gu", NG)) if (a.model == "7b" and not fp8r) else (PMC_TRAFFIC_W8_128 if (a.model == "7b" and fp8r and NG == 128) else None)
         roof = {"bound": "hbm", "kernel": kname + " (decode gate/up GEMV + SiLU*mul, %d rows)" % NG, "achieved": ach,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": k_ms * 1e3, "algorithmic_bytes_per_launch": alg}
+        # the split-K instantiation of the same kernel family: the down projection (K = I, fp32 partial slabs summed by the
+        # next kernel), at the split count the engine's decode step uses
+        if not fp8r and NG > 16:
+            db = eng._decode_bufs(NG, C, S, eng._prefix_chunk(P, S))
+            p_d, ns_d = db["p_d"], db["p_d"].shape[0]
+
+            def dn(l):
+                lib.call("vr2_gemv_bf16", act, act.stride(0), NG, pol[f"l{l}.down_w"], H, pol.shape[f"l{l}.down_w"][1], p_d,
+                         p_d.stride(0) if ns_d > 1 else 0, p_d.stride(-2), ns_d, eng.s)
+            for l in range(Lh):
+                dn(l)
+            L.vr2_event_record(e0, ctypes.c_void_p(eng.s))
+            for _ in range(reps):
+                for l in range(Lh):
+                    dn(l)
+            L.vr2_event_record(e1, ctypes.c_void_p(eng.s))
+            eng.sync()
+            d_ms = elapsed(e0, e1) / (reps * Lh)
+            d_alg = 2 * I * H + NG * I * 2 + ns_d * NG * H * 4
+            extra["roofline_splitk"] = {"bound": "hbm", "kernel": "gemv_ring_kernel<0, %d, 1, 0> (decode down projection, %d rows, %d k-parts)" % (mbs, NG, ns_d),
+                                        "achieved": d_alg / (d_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": d_alg / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get(("down", NG)) if a.model == "7b" else None,
+                                        "avg_launch_us": d_ms * 1e3, "algorithmic_bytes_per_launch": d_alg}
 
         # the largest MFMA-bound kernel of the training phases, measured the same way: the gate/up GEMM + SwiGLU epilogue over
         # the unified row space of one prompt group (T = S + G*C rows), one launch per layer

@@ -21,6 +21,10 @@ extern "C" {
 
 const char* vr2_last_error(void);
 int vr2_version(void);
+/* launch-time kernel-variant knobs for A/B measurements (defaults = the measured best).  key 0: decode GEMV for 16 < M <= 128
+ * rows (0 = LDS-staged kernel of round 1, 1 = one-workgroup-per-CU register-ring kernel with 3 weight chunks in flight per wave,
+ * 2 = the same with 1: the default).  key 1: ablations of that kernel for profiles/ (results wrong).  key 2: x is chunk-major. */
+int vr2_tune_set(int key, int value);
 
 /* ---- GEMMs ------------------------------------------------------------------------------------------------- */
 /* epilogue codes of vr2_gemm_bf16 */

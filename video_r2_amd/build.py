@@ -31,7 +31,7 @@ def build(force=False, verbose=True):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared", "-Wno-unused-value",
            "-I", os.path.join(os.path.dirname(HERE), "include"), "-o", LIB] + srcs
     if verbose:
         print("[video_r2_amd.build]", " ".join(cmd), file=sys.stderr)

@@ -19,6 +19,10 @@ extern "C" const char* vr2_last_error(void);
 void vr2_set_error(const char* fmt, ...);
 int vr2_check_launch(const char* what);
 
+// tuning knobs (api.hip: vr2_tune_set / vr2_tune_get); read on the host at launch time only
+enum { VR2_TUNE_GEMV_VARIANT = 0, VR2_TUNE_GEMV_ABLATE = 1, VR2_TUNE_GEMV_XCHUNK = 2, VR2_TUNE_COUNT = 8 };
+int vr2_tune_get(int key);
+
 #define VR2_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

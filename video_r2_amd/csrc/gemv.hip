@@ -14,6 +14,8 @@
 // and reduce through LDS; an optional grid-level split-K writes separate fp32 partial slabs which the NEXT kernel
 // (add_rmsnorm / rope_append) sums at its launch boundary -- no atomics, bitwise reproducible.
 #include "common.h"
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -285,11 +287,235 @@ __global__ __launch_bounds__(256 * KS) void gemv_lds_kernel(const bf16* __restri
   }
 }
 
+// ---- 16 < M <= 128, K % 64 == 0: one workgroup per CU, weights ring-buffered in REGISTERS, activations in an LDS ring ------
+// What round 1's staged kernel (above) leaves on the table at 64-128 rows, measured on MI355X at the 7B gate/up shape
+// (profiles/r02_gemv_ring.md):
+//   * it issues a chunk's 8 weight loads, waits for them, multiplies, and only then issues the next 8 -- one HBM round trip
+//     per 128 k.  It cannot do better from C++: a global_load_lds in the instruction stream makes hipcc's wait-count pass
+//     turn EVERY later vmcnt / lgkmcnt wait into vmcnt(0) lgkmcnt(0) (the instruction carries an LDS memory operand on a FLAT
+//     encoding, filed under "may return out of order"), so a register prefetch is drained before the first MFMA;
+//   * a CU fetches at most ~40 GB/s in this kernel (weights from HBM + the activation block from L2, half each at 128 rows),
+//     and its 296 workgroups of 128 output columns land one per CU on 216 CUs and TWO on the other 40: those take twice as
+//     long and set the kernel time (256 workgroups: 46 us; 257: 72 us).
+// Here
+//   * the grid is a whole number of workgroups per CU: the weight-tile PAIRS of a launch (gate + up tile of 16 columns, or two
+//     neighbouring tiles) are dealt to G = #CUs x rounds / parts groups, 4-5 pairs each at the 7B gate/up shape; a workgroup
+//     has 8 waves, wave w < count streams pair w (two 1-KiB tiles per 32 k), the others only help staging;
+//   * a wave keeps D chunks (64 k = 4 KiB of weights) in flight in D + 1 register sets that rotate through a loop unrolled
+//     D + 1 times; the activation chunk (16*MB rows x 64 k) lives in a D + 1 slot LDS ring filled D chunks ahead by
+//     direct-to-LDS loads (XOR swizzle through the source address, conflict-free ds_read_b128 fragments);
+//   * every memory instruction and wait of the main loop is inline asm: ONE counted vmcnt for the x chunk (+ s_barrier) and
+//     ONE for the weight set per chunk (vmcnt counts loads and LDS-DMA together, in issue order), counted lgkmcnt per fragment.
+//     The MFMAs are asm too (hipcc hoists bare wait statements over MFMA builtins); gfx950 does not interlock an MFMA result
+//     against a following VALU read, hence the s_nops before compiler-generated code touches the accumulators;
+//   * the main loop is branch-free (hipcc may copy registers at control-flow joins; a copy of an in-flight load destination
+//     reads stale data), so up to D of its load batches name chunks past the end of the part: they re-read the last chunk.
+typedef __attribute__((ext_vector_type(4))) float wreg;    // 16 B of bf16x8 weight / activation fragment in 4 VGPRs
+
+template <int MODE, int MB, int D, int ABL = 0>   // ABL: ablations for profiles/ (1 no x staging, 2 no LDS reads / MFMA, 3 no weight stream, 4 = 1 + 3)
+__global__ __launch_bounds__(512, 2) void gemv_ring_kernel(const bf16* __restrict__ x, int ldx, int xadv, int M,
+                                                           const bf16* __restrict__ Wp, int n_tiles, int N, int K,
+                                                           float* __restrict__ out_f32, long split_stride, int ldo,
+                                                           bf16* __restrict__ out_bf16) {
+  constexpr int NB = D + 1;                          // LDS ring slots == weight register sets
+  static_assert(MB >= 2 && (NB & (NB - 1)) == 0, "ring shape");
+  constexpr int CHUNKB = MB * 2048;                  // 16*MB rows x 64 k bf16
+  constexpr int PIECES = MB * 2;                     // 1-KiB pieces (8 rows x 128 B) of an x chunk
+  constexpr int XP = PIECES >= 8 ? PIECES / 8 : 1;   // pieces staged per wave and chunk (MB = 2: waves 4-7 repeat 0-3)
+  extern __shared__ __attribute__((aligned(16))) char xring[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int ksteps = K >> 5, nchunks = K >> 6;
+  const int parts = gridDim.y, part = blockIdx.y;
+  const int pbase = nchunks / parts, prem = nchunks % parts;
+  const int pc0 = part * pbase + (part < prem ? part : prem);
+  const int n = pbase + (part < prem ? 1 : 0);       // chunks of this part (>= D: host), the same for every wave
+  // this workgroup's weight-tile pairs; wave w streams pair first + w
+  const int pairs = (n_tiles + 1) >> 1, groups = gridDim.x, g = blockIdx.x;
+  const int gbase = pairs / groups, grem = pairs % groups;
+  const int first = g * gbase + (g < grem ? g : grem), count = gbase + (g < grem ? 1 : 0);   // count <= 8 (host)
+  const bool active = wave < count;
+  const int t0 = 2 * (first + (active ? wave : 0)), t1 = (t0 + 1 < n_tiles) ? t0 + 1 : t0;   // odd tile count: last pair streams its tile twice
+  const bool t1_valid = t0 + 1 < n_tiles;
+  // addresses = wave-uniform 64-bit base (SGPR pair, advanced per chunk) + a per-lane 32-bit offset that never changes
+  const char* w0 = (const char*)(Wp + ((long)t0 * ksteps + 2 * pc0) * 512);   // + 2 KiB per chunk
+  const char* w1 = (const char*)(Wp + ((long)t1 * ksteps + 2 * pc0) * 512);
+  const unsigned wlane = lane * 16;
+  const char* xb = (const char*)x + (long)pc0 * xadv;                           // + xadv bytes per chunk (128 row-major)
+  unsigned xoff[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int row = ((wave * XP + i) % PIECES) * 8 + (lane >> 3), c = lane & 7;
+    const int m = row < M ? row : M - 1;             // rows past M: a finite copy of the last row, never stored
+    xoff[i] = (unsigned)(m * ldx + ((c ^ (row & 7)) << 3)) * 2u;               // XOR swizzle through the source address
+  }
+  int staged = 0, loaded = 0;                        // chunks handed to the LDS ring / to the register sets so far
+  auto stage = [&]() {
+    char* dst = xring + (staged & (NB - 1)) * CHUNKB;
+#pragma unroll
+    for (int i = 0; i < XP; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + ((ABL == 1 || ABL == 4) ? 0u : xoff[i])),
+                                       (__attribute__((address_space(3))) void*)(dst + ((wave * XP + i) % PIECES) * 1024), 16, 0, 0);
+    ++staged;
+    xb += staged < n ? xadv : 0;                     // phantom stages re-read the last chunk
+  };
+  const unsigned ring_u32 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)xring;
+  const unsigned frag0 = ring_u32 + r * 128 + ((q ^ (r & 7)) << 4);            // k-step 0 of a chunk: 16-B slot q
+  const unsigned frag1 = ring_u32 + r * 128 + (((4 + q) ^ (r & 7)) << 4);      // k-step 1: slot 4 + q
+
+  wreg acc0[MB], acc1[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) { acc0[mb] = wreg{0.f, 0.f, 0.f, 0.f}; acc1[mb] = wreg{0.f, 0.f, 0.f, 0.f}; }
+  wreg wa[NB][2], wb[NB][2];
+#define VR2_LOADW(S_)                                                                                                   \
+  do {                                                                                                                  \
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wa[S_][0]) : "v"(wlane), "s"(w0) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wb[S_][0]) : "v"(wlane), "s"(w1) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=v"(wa[S_][1]) : "v"(wlane), "s"(w0) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=v"(wb[S_][1]) : "v"(wlane), "s"(w1) : "memory");   \
+    ++loaded;                                                                                                           \
+    { const int adv = (loaded < n && ABL != 3 && ABL != 4) ? 2048 : 0; w0 += adv; w1 += adv; }                                      \
+  } while (0)
+
+  // The whole k loop for one kind of wave.  ACTIVE waves stream a tile pair: 4 weight loads + XP stage ops per chunk; helper
+  // waves (wave >= count) only stage and keep the barriers: XP ops per chunk.  The counted waits follow from the issue order
+  // [weight loads of chunk c + D][wait x chunk c + barrier][stage chunk c + D][multiply chunk c].
+  auto kloop = [&](auto act) {
+    constexpr bool ACTIVE = decltype(act)::value;
+    constexpr int WL = ACTIVE ? 4 : 0;
+    constexpr int X_YOUNGER = D * WL + (D - 1) * XP;   // VMEM ops issued after the LDS-DMA of chunk c before its wait
+    constexpr int W_YOUNGER = D * WL + (D + 1) * XP;   // ... after the weight loads of chunk c before theirs
+    static_assert(W_YOUNGER <= 63, "vmcnt is 6 bits");
+    auto& A0 = acc0; auto& A1 = acc1; auto& WA = wa; auto& WB = wb;   // (asm operands alone do not capture in a generic lambda)
+    // one chunk.  STEADY: the load batches it names are issued (real or phantom) and the queue history is the steady one, so
+    // the waits are counted; otherwise (the last <= D chunks of the part) nothing is in flight any more.
+    auto chunk = [&](int cc, auto jc, auto steady) {
+      constexpr int j = decltype(jc)::value;
+      constexpr bool STEADY = decltype(steady)::value;
+      auto& C0 = A0; auto& C1 = A1; auto& CA = WA; auto& CB = WB;       // (same capture quirk, one lambda level down)
+      if constexpr (STEADY && ACTIVE) VR2_LOADW((j + D) % NB);   // chunk cc + D into the set chunk cc - 1 was multiplied from
+      // the barrier publishes every wave's pieces of x chunk cc and retires ring slot cc - 1, refilled with chunk cc + D
+      if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(X_YOUNGER) : "memory");
+      else asm volatile("s_barrier" ::: "memory");
+      if constexpr (STEADY) stage();
+      if constexpr (ACTIVE) {
+        const unsigned boff = (unsigned)(cc & (NB - 1)) * CHUNKB;
+#pragma unroll
+        for (int i = 0; i < (ABL == 2 ? 0 : 2); ++i) {
+          const unsigned a = (i == 0 ? frag0 : frag1) + boff;
+          wreg b[MB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[mb]) : "v"(a), "n"(mb * 2048) : "memory");
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            if (i == 0 && mb == 0 && STEADY)           // first use of this weight set
+              asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_YOUNGER) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"
+                         : "+v"(C0[mb]), "+v"(C1[mb])
+                         : "v"(CA[j][i]), "v"(CB[j][i]), "v"(b[mb]), "n"(MB - 1 - mb));
+          }
+        }
+      }
+    };
+    // prologue = the load halves of D steady iterations, in steady order, so the counted waits hold from chunk 0 on
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      if constexpr (ACTIVE) VR2_LOADW(j);
+      stage();
+    }
+    // main loop: whole groups of NB steady chunks; covers chunks 0 .. S' - 1, S' = (n - D) rounded up to a multiple of NB,
+    // every one of them a real chunk (S' <= n because NB = D + 1)
+    int cb = 0;
+    for (; cb < n - D; cb += NB) {
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        (chunk(cb + J, std::integral_constant<int, J>{}, std::true_type{}), ...);
+      }(std::make_integer_sequence<int, NB>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // nothing in flight past this point
+    // the last n - S' <= D chunks: their weights and activations were loaded by the main loop
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+      ((cb + J < n ? (chunk(cb + J, std::integral_constant<int, J>{}, std::false_type{}),
+                      (void)({ asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); 0; }))
+                   : (void)0), ...);
+    }(std::make_integer_sequence<int, D>{});
+  };
+  if (active) kloop(std::true_type{});
+  else { kloop(std::false_type{}); return; }
+#undef VR2_LOADW
+  // D layout (16x16): lane holds col = m = lane&15, rows n = 4*(lane>>4)+i of the tile
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const long row = mb * 16 + r;
+    if (row >= M) continue;
+    if (MODE == 0) {
+      float* o = out_f32 + (long)blockIdx.y * split_stride + row * ldo;
+      const int na = t0 * 16 + 4 * q, nb = t1 * 16 + 4 * q;
+      if (na < N) *reinterpret_cast<float4*>(o + na) = make_float4(acc0[mb][0], acc0[mb][1], acc0[mb][2], acc0[mb][3]);
+      if (t1_valid && nb < N) *reinterpret_cast<float4*>(o + nb) = make_float4(acc1[mb][0], acc1[mb][1], acc1[mb][2], acc1[mb][3]);
+    } else {
+      const int nn = (t0 >> 1) * 16 + 4 * q;         // gate tile t0 (even), up tile t0 + 1 -> output column block t0/2
+      if (t1_valid && nn < N) {
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float gt = acc0[mb][i]; o[i] = f2bf((gt / (1.0f + expf(-gt))) * acc1[mb][i]); }
+        *reinterpret_cast<bf16x4*>(out_bf16 + row * ldo + nn) = o;
+      }
+    }
+  }
+}
+
+// groups per k part for the ring kernel: a whole number of workgroups per CU over all parts, <= 8 tile pairs per workgroup
+inline int ring_groups(int pairs, int parts) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    ncu = prop.multiProcessorCount;
+  }
+  const long units = (long)pairs * parts;
+  const int rounds = (int)((units + 8L * ncu - 1) / (8L * ncu));
+  int groups = (ncu * rounds) / parts;
+  if (groups < 1) groups = 1;
+  if (groups > pairs) groups = pairs;
+  while ((pairs + groups - 1) / groups > 8) ++groups;
+  return groups;
+}
+
 template <int MODE>
 void launch_gemv(dim3 grid, hipStream_t st, const bf16* x, int ldx, int M, const bf16* Wp, int n_tiles, int N, int K, float* of,
                  long split_stride, int ldo, bf16* ob) {
   if (M <= 16) {
     hipLaunchKernelGGL((gemv16_kernel<MODE, 1, 4>), grid, dim3(256), 0, st, x, ldx, M, Wp, n_tiles, N, K, of, split_stride, ldo, ob);
+    return;
+  }
+  const int variant = vr2_tune_get(VR2_TUNE_GEMV_VARIANT);
+  const int pairs = (n_tiles + 1) / 2;
+  const int groups = (variant > 0 && K % 64 == 0 && (K / 64) / (int)grid.y >= 4) ? ring_groups(pairs, (int)grid.y) : 0;
+  if (groups > 0) {
+    // register-ring kernel: one workgroup per CU and round, <= 8 tile pairs each, grid.y parts of whole 64-k chunks
+    const dim3 gr((unsigned)groups, grid.y);
+    // experiment knob: x given chunk-major ([K/64][M][64]: every 64-k chunk of all rows contiguous) instead of row-major
+    const bool chunk_major = vr2_tune_get(VR2_TUNE_GEMV_XCHUNK) != 0;
+    const int rldx = chunk_major ? 64 : ldx, xadv = chunk_major ? M * 128 : 128;
+#define VR2_RING_LAUNCH(MB_, D_, ...)                                                                                           \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_ring_kernel<MODE, MB_, D_ __VA_OPT__(,) __VA_ARGS__>),  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (D_ + 1) * MB_ * 2048); attr = true; }   \
+    hipLaunchKernelGGL((gemv_ring_kernel<MODE, MB_, D_ __VA_OPT__(,) __VA_ARGS__>), gr, dim3(512), (D_ + 1) * MB_ * 2048, st, x, \
+                       rldx, xadv, M, Wp, n_tiles, N, K, of, split_stride, ldo, ob);                                            \
+  } while (0)
+    const int abl = vr2_tune_get(VR2_TUNE_GEMV_ABLATE);
+    if (abl > 0 && MODE == 1 && M > 64) {            // profiles/: which resource bounds the kernel (results are wrong)
+      if (abl == 1) VR2_RING_LAUNCH(8, 1, 1); else if (abl == 2) VR2_RING_LAUNCH(8, 1, 2); else if (abl == 3) VR2_RING_LAUNCH(8, 1, 3); else VR2_RING_LAUNCH(8, 1, 4);
+    } else if (variant == 2) {                       // shallow ring (2 slots, one chunk in flight): A/B reference point
+      if (M <= 32) VR2_RING_LAUNCH(2, 1); else if (M <= 64) VR2_RING_LAUNCH(4, 1); else VR2_RING_LAUNCH(8, 1);
+    } else {
+      if (M <= 32) VR2_RING_LAUNCH(2, 3); else if (M <= 64) VR2_RING_LAUNCH(4, 3); else VR2_RING_LAUNCH(8, 3);
+    }
+#undef VR2_RING_LAUNCH
     return;
   }
   // LDS-staged variant, 8 weight tiles (128 output rows) per workgroup; two k groups per workgroup when the part is long

@@ -146,10 +146,13 @@ int64_t vr2_sample_ws_bytes(int64_t G);
 int vr2_lse_gather(const void* logits_f32, int64_t ldl, int64_t R, int64_t V, const void* tok_i32, float temperature,
                    void* logp_f32, void* lse_f32, void* stream);
 /* GRPO loss + d loss / d logp + metrics (grpo_trainer.py:1099-1177, K16).  loss_type: 0 grpo 1 bnpo 2 dr_grpo 3 gmpo
- * 4 mapo 5 mapo_bnpo.  out8 = {loss, kl, clip_low, clip_high, clip_region, n_tokens, -, -} */
+ * 4 mapo 5 mapo_bnpo.  norm_rows: rows per normalisation block of the token-mean aggregations (bnpo, mapo_bnpo) and of the
+ * kl / clip metrics = the reference's per-rank micro-batch (per_device_train_batch_size completions; blocks are averaged as
+ * its ranks and accumulation steps are); <= 0: the whole batch is one block.
+ * out8 = {loss, kl, clip_low, clip_high, clip_region, n_tokens, -, -} */
 int vr2_grpo_loss(const void* logp_f32, const void* ref_logp_f32, const void* old_logp_f32, const void* mask_i32,
                   const void* adv_f32, int64_t B, int64_t C, float beta, float eps_low, float eps_high, int loss_type,
-                  float max_completion_length, void* out8_f32, void* dlogp_f32, void* stream);
+                  float max_completion_length, int64_t norm_rows, void* out8_f32, void* dlogp_f32, void* stream);
 
 /* ---- update path (backward + optimiser; autograd of the HF forward reached from grpo_trainer.py:1094-1096, K17/K18) ---- */
 /* weight gradient: C[M][N] f32 (+)= sum_k A[k][m] B[k][n]; A = dY [tokens][out], B = X [tokens][in] (both row-major bf16) */

@@ -4,7 +4,7 @@ Test infrastructure only (see oracle/__init__.py).
 Follows /root/reference/train/src/trainer/grpo_trainer.py: reward aggregation + advantages :907-981,
 loss :1085-1178, nanstd/nanmin/nanmax :180-253.  The reference trainer itself is not importable here
 (trl / deepspeed / peft absent) and ships no tests: beyond the hand-computed known answers in
-tests/test_oracle_grpo.py this file is "parity unpinned".
+tests/test_host_cpu.py (advantages, loss vs torch autograd, the 8-ranks-x-1-completion emulation) this file is "parity unpinned".
 """
 from __future__ import annotations
 
@@ -104,12 +104,31 @@ def advantages(rewards_per_func, reward_weights, num_generations, loss_type="bnp
 
 
 def loss(per_token_logps, completion_mask, advantages, *, ref_per_token_logps=None, old_per_token_logps=None,
-         beta=0.04, epsilon_low=0.2, epsilon_high=0.2, loss_type="bnpo", max_completion_length=None):
-    """grpo_trainer.py:1099-1177 in float64-free float32 numpy.
+         beta=0.04, epsilon_low=0.2, epsilon_high=0.2, loss_type="bnpo", max_completion_length=None, norm_rows=0):
+    """grpo_trainer.py:1099-1177 in float64-free float32 numpy, for ONE rank's micro-batch (norm_rows = 0), or -- norm_rows =
+    u > 0 -- for the rows cut into micro-batches of u consecutive rows whose losses / metrics are then averaged, which is what
+    the reference's ranks and accumulation steps compute together (each rank: :1146-1177 on per_device_train_batch_size rows;
+    DDP and Trainer average the ranks' and steps' losses; gather_for_metrics(...).nanmean() the metrics).
 
     Returns dict(loss, per_token_loss [B,C], dloss_dlogp [B,C] (analytic gradient wrt per_token_logps with
     old = logp.detach() when old is None), kl, clip_low, clip_high, clip_region).
     """
+    if norm_rows and 0 < norm_rows < np.asarray(per_token_logps).shape[0]:
+        u, Bt = int(norm_rows), np.asarray(per_token_logps).shape[0]
+        parts = []
+        for b0 in range(0, Bt, u):
+            sl = slice(b0, b0 + u)
+            parts.append(loss(np.asarray(per_token_logps)[sl], np.asarray(completion_mask)[sl], np.asarray(advantages)[sl],
+                              ref_per_token_logps=None if ref_per_token_logps is None else np.asarray(ref_per_token_logps)[sl],
+                              old_per_token_logps=None if old_per_token_logps is None else np.asarray(old_per_token_logps)[sl],
+                              beta=beta, epsilon_low=epsilon_low, epsilon_high=epsilon_high, loss_type=loss_type,
+                              max_completion_length=max_completion_length))
+        n = F32(len(parts))
+        with np.errstate(invalid="ignore"):
+            mean = lambda k: (None if parts[0][k] is None else F32(np.nanmean(np.asarray([p[k] for p in parts], dtype=F32))))  # noqa: E731
+        return dict(loss=F32(sum(p["loss"] for p in parts) / n), per_token_loss=np.concatenate([p["per_token_loss"] for p in parts]),
+                    dloss_dlogp=np.concatenate([p["dloss_dlogp"] for p in parts]) / n, kl=mean("kl"), clip_low=mean("clip_low"),
+                    clip_high=mean("clip_high"), clip_region=mean("clip_region"))
     lp = np.asarray(per_token_logps, dtype=F32)
     mask = np.asarray(completion_mask).astype(F32)
     A = np.asarray(advantages, dtype=F32)[:, None]

@@ -1,0 +1,87 @@
+"""GPU: the shell entry point trains.  `bash train/scripts/train_grpo.sh` (the reference's launch line: torchrun ->
+src/train/train_grpo.py, /root/reference/train/scripts/train_grpo.sh:41-80) on a tiny HF-layout model directory, a 6-row JSON
+dataset of array clips with one subtitle file, overlays on: three optimiser steps with checkpoints every two, then a second
+launch that must resume from checkpoint-2 (train_grpo.py:184-187) instead of starting over."""
+import ast
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import model as om
+from tests.helpers import to_engine_cfg
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(env, *flags):
+    r = subprocess.run(["bash", os.path.join(ROOT, "train", "scripts", "train_grpo.sh"), *flags], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n---- stderr ----\n" + r.stderr[-6000:]
+    steps = [ast.literal_eval(ln) for ln in r.stdout.splitlines() if ln.startswith("{'step'")]
+    return steps, r.stderr
+
+
+def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
+    from video_r2_amd.model import VideoR2Model
+    ocfg = om.cfg_tiny(2)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), om.make_weights(ocfg, seed=41), device="cuda:0")
+    model_dir = tmp_path / "sft_model"
+    m.save_pretrained(str(model_dir))
+    (model_dir / "generation_config.json").write_text("{}")               # a processor-side file that must travel with the weights
+    del m
+    clips, subs = tmp_path / "videos", tmp_path / "subs"
+    (clips / "set").mkdir(parents=True)
+    (subs / "set").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    rows = []
+    for i in range(6):
+        np.savez(clips / "set" / f"c{i}.npz", frames=rng.integers(0, 256, size=(60, 56, 84, 3), dtype=np.uint8), fps=np.float32(30.0))
+        rows.append({"video": f"set/c{i}.npz", "key_frame": "",
+                     "conversations": [{"from": "human", "value": f"<video>\nQuestion {i}?\nA. yes\nB. no"},
+                                       {"from": "gpt", "value": "<think>..</think><answer>B</answer>"}],
+                     "temporal_grounding": {"00:00-00:01": "something happens."}})
+    (subs / "set" / "c0.srt").write_text("1\n00:00:00,000 --> 00:00:02,000\nhello world\n")
+    data = tmp_path / "grpo.json"
+    data.write_text(json.dumps(rows))
+    # the user's reward module (the --reward_module seam): the built-in rewards plus one that varies inside a group even for a
+    # random-init model, so that advantages -- and gradients -- are not all zero
+    (tmp_path / "my_reward_funcs.py").write_text(
+        "from video_r2_amd.rewards import accuracy_reward, format_reward  # noqa: F401\n\n\n"
+        "def text_length_reward(completions, assistant, temporal_grounding, **kwargs):\n"
+        "    assert all(isinstance(a, dict) and 'content' in a for a in assistant) and len(temporal_grounding) == len(completions)\n"
+        "    assert kwargs['prompts'][0][1]['content'][1]['text'].startswith('Question')\n"
+        "    return [float(i % 2) + 0.1 * (len(c[0]['content']) % 3) for i, c in enumerate(completions)]\n")
+    out_dir = tmp_path / "out"
+    env = dict(os.environ, PYTHONPATH=f"{tmp_path}:{os.environ.get('PYTHONPATH', '')}", NUM_DEVICES="1", MODEL_NAME=str(model_dir), DATA_PATH=str(data), DATA_FOLDER=str(clips),
+               SUBTITLES_FOLDER=str(subs), OUTPUT_DIR=str(out_dir), FPS_MAX_FRAMES="4", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    flags = ["--num_generations", "4", "--per_device_train_batch_size", "4", "--max_completion_length", "12",
+             "--reward_module", "my_reward_funcs", "--reward_func_names", "accuracy_reward,format_reward,text_length_reward",
+             "--reward_weights", "1.0,1.0,0.5", "--logging_steps", "1",
+             "--save_steps", "2", "--dataloader_num_workers", "2", "--learning_rate", "1e-3", "--video_min_pixels", "4704",
+             "--video_max_pixels", "4704", "--log_completions", "True"]
+    steps, err = _launch(env, *flags, "--max_steps", "3")
+    assert [s["step"] for s in steps] == [1, 2, 3], err[-3000:]
+    for s in steps:
+        assert np.isfinite(s["loss"]) and s["grad_norm"] > 0 and s["completions/mean_length"] > 0
+        for k in ("reward", "reward_std", "rewards/accuracy_reward/mean", "rewards/accuracy_reward/std", "rewards/text_length_reward/std",
+                  "kl", "clip_ratio/region_mean", "learning_rate", "num_tokens"):
+            assert k in s, k
+    assert "ByteTokenizer" in err and "reward functions ['accuracy_reward', 'format_reward', 'text_length_reward']" in err and "from my_reward_funcs" in err
+    assert sorted(p for p in os.listdir(out_dir) if p.startswith("checkpoint-")) == ["checkpoint-2"]
+    for d in (out_dir, out_dir / "checkpoint-2"):
+        assert (d / "model.safetensors").exists() and (d / "config.json").exists() and (d / "generation_config.json").exists()
+    assert (out_dir / "checkpoint-2" / "trainer_state.pt").exists()
+    # second launch, one more step allowed: resumes after step 2 (steps 3 and 4 run, not 1..4) and keeps --save_total_limit 2
+    steps2, err2 = _launch(env, *flags, "--max_steps", "4")
+    assert "resumed from" in err2 and "checkpoint-2 at step 2" in err2
+    assert [s["step"] for s in steps2] == [3, 4]
+    assert sorted(p for p in os.listdir(out_dir) if p.startswith("checkpoint-")) == ["checkpoint-2", "checkpoint-4"]
+    # the resumed step 3 sees the same prompts and the same sampling seed as the first run's step 3, from the same weights
+    assert steps2[0]["completions/mean_length"] == steps[2]["completions/mean_length"]
+    assert steps2[0]["loss"] == pytest.approx(steps[2]["loss"], rel=1e-5, abs=1e-7)

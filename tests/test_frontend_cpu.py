@@ -1,0 +1,191 @@
+"""CPU: the host front end of the entry point -- dataset rows -> chat prompts (grpo_dataset.py:107-186) and prompts -> token
+ids + uint8 clips (grpo_trainer.py:755-767 through vision_process.py).  Integer artefacts are checked exactly (frame
+indices against torch.linspace as the reference computes them, token layout, resize dimensions); the PIL overlays have no
+runnable reference here (vision_process.py imports torchvision, absent): their geometry is checked, their glyph pixels are
+"parity unpinned"."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from video_r2_amd import params
+from video_r2_amd.config import ModelConfig
+from video_r2_amd.host import dataset as hd
+from video_r2_amd.host import frames as hf
+from video_r2_amd.host import frontend as fe
+
+
+def _rows():
+    return [
+        {"video": "clips/a.npz", "key_frame": "",
+         "conversations": [{"from": "human", "value": "<video>\nWhat happens first?\nA. x\nB. y"},
+                           {"from": "gpt", "value": "<think>t</think><answer>B</answer>"}],
+         "temporal_grounding": {"00:01-00:03": "a person waves."}, "temporal_captions": {"00:00-00:05": "c"}},
+        {"video": ["clips/a.npz", "clips/b.npz"], "key_frame": ["", "k"],
+         "conversations": [{"from": "human", "value": "Compare.<video>"}, {"from": "gpt", "value": "<answer>3</answer>"}]},
+    ]
+
+
+def test_dataset_rows_become_reference_shaped_examples(tmp_path):
+    (tmp_path / "subs" / "clips").mkdir(parents=True)
+    (tmp_path / "subs" / "clips" / "a.srt").write_text("1\n00:00:00,000 --> 00:00:02,000\nhello\n")
+    path = tmp_path / "d.json"
+    path.write_text(json.dumps(_rows()))
+    a = params.parse_args(["--data_path", str(path), "--image_folder", str(tmp_path / "videos"), "--video_subtitles_folder",
+                           str(tmp_path / "subs"), "--video_max_pixels", str(360 * 420), "--fps", "2.0"])
+    ds = hd.make_grpo_data_module("m", None, a)["train_dataset"]
+    assert len(ds) == 2
+    ex = ds[0]
+    assert list(ex) == ["prompt", "assistant", "temporal_captions", "temporal_grounding"]
+    sys_msg, user = ex["prompt"]
+    assert sys_msg == {"role": "system", "content": "You are a helpful assistant."} and user["role"] == "user"
+    vid, text = user["content"]
+    assert vid == {"type": "video", "video": str(tmp_path / "videos" / "clips/a.npz"), "subtitles": str(tmp_path / "subs" / "clips" / "a.srt"),
+                   "key_frame": "", "fps": 2.0, "min_pixels": 100352, "max_pixels": 151200}
+    assert text == {"type": "text", "text": "What happens first?\nA. x\nB. y"}          # "<video>\n" removed
+    assert ex["assistant"] == {"role": "gpt", "content": "<think>t</think><answer>B</answer>"}   # the answer TURN, role as in the file
+    assert ex["temporal_grounding"] == {"00:01-00:03": "a person waves."}
+    ex2 = ds[1]
+    assert [c["type"] for c in ex2["prompt"][1]["content"]] == ["video", "video", "text"]
+    assert ex2["prompt"][1]["content"][1]["subtitles"] is None and ex2["prompt"][1]["content"][1]["key_frame"] == "k"
+    assert ex2["prompt"][1]["content"][2]["text"] == "Compare." and ex2["temporal_grounding"] == {} and ex2["temporal_captions"] == {}
+    # TAR reads the question at prompts[i][1]["content"][1]["text"] (reward_funcs.py:92)
+    assert ex["prompt"][1]["content"][1]["text"].startswith("What happens")
+
+
+def test_frame_range_and_time_helpers():
+    assert fe.frame_range({}, 300, 30.0) == (0, 299, 300)
+    assert fe.frame_range({"video_start": 1.0, "video_end": 4.0}, 300, 30.0) == (30, 120, 91)
+    assert fe.frame_range({"video_end": 100.0}, 300, 30.0) == (0, 299, 300)
+    assert fe.frame_range({"video_start": 0.51}, 100, 10.0) == (6, 99, 94)          # ceil on the start, floor on the end
+    with pytest.raises(ValueError):
+        fe.frame_range({"video_start": 5.0, "video_end": 5.0}, 300, 30.0)
+    assert fe.format_hhmmss(0.9) == "00:00:00" and fe.format_hhmmss(3725.7) == "01:02:05"
+
+
+def test_srt_parsing_and_cue_lookup(tmp_path):
+    srt = tmp_path / "a.srt"
+    srt.write_text("1\r\n00:00:01,000 --> 00:00:02,500\r\n<i>hello</i> there\r\nsecond line\r\n\r\n"
+                   "garbage block without timing\n\n"
+                   "00:00:05,000 --> 00:00:06,000\nno index line\n\n3\n00:00:03,000 --> 00:00:04,000\n\n")
+    cues = fe.parse_srt(str(srt))
+    assert cues == [(1.0, 2.5, ["hello there", "second line"]), (5.0, 6.0, ["no index line"])]   # sorted, tags stripped, empty cue dropped
+    idx = fe.SubtitleIndex(cues)
+    assert idx.get(0.5) == (None, 0)
+    assert idx.get(0.96) == ("hello there\nsecond line", 0)                        # 50 ms tolerance before the first cue
+    assert idx.get(2.54, 0) == ("hello there\nsecond line", 0)
+    assert idx.get(3.0, 0) == (None, 0)
+    assert idx.get(5.5, 0) == ("no index line", 1)
+    assert fe.SubtitleIndex([]).get(1.0, 3) == (None, 3)
+
+
+def test_overlays_touch_only_their_corner_and_are_deterministic():
+    rng = np.random.default_rng(0)
+    frame = rng.integers(100, 140, size=(240, 320, 3), dtype=np.uint8)            # mid-grey noise: neither dark nor red -> red text
+    assert fe.stamp_colour(frame) == (255, 0, 0)
+    assert fe.stamp_colour(np.zeros((50, 50, 3), np.uint8)) == (255, 255, 255)
+    red = np.zeros((50, 250, 3), np.uint8); red[..., 0] = 200
+    assert fe.stamp_colour(red) == (255, 255, 255)
+    a = fe.draw_timestamp(frame, "00:01:07")
+    b = fe.draw_timestamp(frame, "00:01:07")
+    assert a.dtype == np.uint8 and a.shape == frame.shape and np.array_equal(a, b)
+    changed = np.argwhere((a != frame).any(-1))
+    assert len(changed) > 20 and changed[:, 0].max() < 60 and changed[:, 1].max() < 200     # top-left only (font 16 px, margin 5)
+    s = fe.draw_subtitle(frame, "a subtitle that is long enough to be wrapped over more than one single line of text, twice over")
+    ch = np.argwhere((s != frame).any(-1))
+    assert len(ch) > 500 and ch[:, 0].min() > 120 and ch[:, 0].max() <= 240 - 6     # bottom box, 6 px margin (font 20 px)
+    assert fe.draw_subtitle(frame, "") is frame
+
+
+def _clip(tmp_path, name="a.npz", t=90, h=72, w=128, fps=30.0):
+    rng = np.random.default_rng(len(name))
+    fr = rng.integers(0, 256, size=(t, h, w, 3), dtype=np.uint8)
+    np.savez(tmp_path / name, frames=fr, fps=np.float32(fps))
+    return fr
+
+
+def test_read_video_picks_the_reference_frames(tmp_path, monkeypatch):
+    monkeypatch.setenv("FPS_MAX_FRAMES", "32")
+    monkeypatch.delenv("WRITE_TIMESTAMPS_ON_FRAMES", raising=False)
+    monkeypatch.delenv("WRITE_SUBTITLES_ON_FRAMES", raising=False)
+    fr = _clip(tmp_path, t=90, fps=30.0)
+    ele = {"type": "video", "video": str(tmp_path / "a.npz"), "fps": 2.0, "min_pixels": 100352, "max_pixels": 151200, "subtitles": None}
+    frames, sfps, dims = fe.read_video(ele)
+    # 90 frames @ 30 fps sampled at 2 fps -> 6 frames (even, within [4, 32]); indices as torch.linspace(...).round() gives them
+    want = torch.linspace(0, 89, 6).round().long().tolist()
+    assert frames.shape == (6, 3, 72, 128) and frames.dtype == torch.uint8
+    assert np.array_equal(frames.permute(0, 2, 3, 1).numpy(), fr[want])
+    assert sfps == pytest.approx(6 / 90 * 30.0)
+    assert dims == hf.video_resize_dims(6, 72, 128, ele) and dims[0] % 28 == 0 and dims[1] % 28 == 0
+    assert dims[0] * dims[1] >= 100352 * 0.9                                       # upscaled to the min-pixel floor
+    # overlays on: the stamped frames differ from the raw ones in the top-left corner only, time = source index / fps
+    monkeypatch.setenv("WRITE_TIMESTAMPS_ON_FRAMES", "True")
+    stamped, _, _ = fe.read_video(ele)
+    diff = (stamped != frames).any(1)
+    assert diff.any() and not diff[:, 40:, :].any()
+    # a .npy clip with the fps beside it
+    np.save(tmp_path / "b.npy", fr)
+    (tmp_path / "b.npy.json").write_text('{"fps": 30.0}')
+    monkeypatch.delenv("WRITE_TIMESTAMPS_ON_FRAMES")
+    f2, s2, _ = fe.read_video({**ele, "video": "file://" + str(tmp_path / "b.npy")})
+    assert torch.equal(f2, frames) and s2 == sfps
+    with pytest.raises(RuntimeError, match="no video decoder"):
+        fe.open_clip(str(tmp_path / "missing.mp4"))
+
+
+def test_chat_layout_and_tokenisers(tmp_path):
+    prompt = [{"role": "system", "content": "You are a helpful assistant."},
+              {"role": "user", "content": [{"type": "video", "video": "v"}, {"type": "text", "text": "Q?"}]}]
+    text = fe.render_chat(prompt)
+    assert text == ("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n<|vision_start|><|video_pad|><|vision_end|>Q?"
+                    "<|im_end|>\n<|im_start|>assistant\n")
+    assert fe.render_chat(prompt[1:]).startswith("<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n<|im_start|>user\n")
+    cfg = ModelConfig.tiny()
+    bt = fe.ByteTokenizer(cfg)
+    ids = bt.encode(text)
+    assert ids.count(cfg.video_token_id) == 1 and ids.count(cfg.vision_start_token_id) == 1 and ids.count(cfg.eos_token_id) == 2
+    assert bt.decode(ids, skip_special_tokens=False) == text
+    assert bt.decode(ids) == "system\nYou are a helpful assistant.\nuser\nQ?\nassistant\n"
+    assert bt.decode([104, 105, cfg.eos_token_id, cfg.pad_token_id, 999, cfg.pad_token_id]) == "hi"     # pads / unknown ids vanish
+    assert bt.decode("héllo".encode()) == "héllo"
+    # tokenizer.json of a model directory through the `tokenizers` runtime
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    vocab = {"[UNK]": 0, "Q": 1, "?": 2, "system": 3, "user": 4, "assistant": 5, "hello": 6}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.add_special_tokens(["<|endoftext|>", "<|im_start|>", "<|im_end|>", "<|vision_start|>", "<|vision_end|>", "<|video_pad|>"])
+    tk.save(str(tmp_path / "tokenizer.json"))
+    ht = fe.load_tokenizer(str(tmp_path), cfg)
+    assert isinstance(ht, fe.HFTokenizer) and ht.eos_token_id == tk.token_to_id("<|im_end|>") and ht.pad_token_id == tk.token_to_id("<|endoftext|>")
+    e = ht.encode("<|im_start|>user\n<|vision_start|><|vision_end|>hello Q?<|im_end|>")
+    assert e == [tk.token_to_id("<|im_start|>"), 4, tk.token_to_id("<|vision_start|>"), tk.token_to_id("<|vision_end|>"), 6, 1, 2, tk.token_to_id("<|im_end|>")]
+    assert ht.decode(e) == "user hello Q ?"
+    assert isinstance(fe.load_tokenizer(str(tmp_path / "nope"), cfg), fe.ByteTokenizer)
+
+
+def test_processing_front_end_builds_the_prompt_the_engine_expects(tmp_path, monkeypatch):
+    monkeypatch.delenv("WRITE_TIMESTAMPS_ON_FRAMES", raising=False)
+    monkeypatch.delenv("WRITE_SUBTITLES_ON_FRAMES", raising=False)
+    _clip(tmp_path, t=60, h=56, w=84, fps=30.0)
+    cfg = ModelConfig.tiny()
+    tok = fe.ByteTokenizer(cfg)
+    pf = fe.ProcessingFrontEnd(cfg, tok)
+    ele = {"type": "video", "video": str(tmp_path / "a.npz"), "fps": 2.0, "min_pixels": 56 * 84, "max_pixels": 56 * 84, "subtitles": None}
+    ex = {"prompt": [{"role": "system", "content": "S."}, {"role": "user", "content": [ele, {"type": "text", "text": "Why?"}]}]}
+    out = pf(ex)
+    (frames, dims), = out["videos"]
+    assert frames.shape == (4, 3, 56, 84) and dims == (56, 84)                     # 60 frames @ 30 fps at 2 fps -> 4 frames
+    n_vid = 2 * (56 // 14) * (84 // 14) // 4
+    ids = out["input_ids"].tolist()
+    assert ids.count(cfg.video_token_id) == n_vid
+    at = ids.index(cfg.video_token_id)
+    assert ids[at - 1] == cfg.vision_start_token_id and ids[at + n_vid] == cfg.vision_end_token_id
+    assert tok.decode(ids[at + n_vid + 1:]) == "Why?\nassistant\n"
+    assert out["second_per_grid_ts"] == [pytest.approx(2 / (4 / 60 * 30.0))]
+    assert out["decode"](torch.tensor([[72, 105, cfg.eos_token_id, cfg.pad_token_id], [79, 75, 33, 33]])) == ["Hi", "OK!!"]
+    # a prompt whose text count of video placeholders and video elements disagree is refused
+    bad = {"prompt": [{"role": "user", "content": [{"type": "text", "text": "no clip but a <|video_pad|> string"}]}]}
+    with pytest.raises(ValueError, match="video placeholders"):
+        pf(bad)

@@ -41,7 +41,8 @@ def test_train_grpo_sh_emits_flags_the_parser_accepts(tmp_path):
     a = params.parse_args(argv[i + 1:])
     assert a.model_id == "/m" and a.num_generations == 8 and a.max_completion_length == 1024 and a.beta == 0.04
     assert a.video_max_pixels == 360 * 420 and a.max_steps == 3 and a.freeze_llm is False and a.freeze_vision_tower is True
-    assert a.reward_func_names == "accuracy_reward,format_reward" and "deepspeed" in a.ignored
+    assert a.reward_func_names == "accuracy_reward,format_reward,temporal_grounding_sentence_embedding_consistency_reward"
+    assert a.reward_weights == "1.0,1.0,1.0" and "deepspeed" in a.ignored and a.fps == 2.0 and a.save_steps == 500
 
 
 def test_reward_plugin_discovery_and_shipped_functions():
@@ -55,9 +56,74 @@ def test_reward_plugin_discovery_and_shipped_functions():
     comp = lambda s: [{"role": "assistant", "content": s}]
     cs = [comp("<think>a</think> <answer>B</answer>"), comp("<answer>B</answer>"), comp("<think>x</think><answer>3.14</answer>tail")]
     assert rewards.format_reward(completions=cs) == [1.0, 0.0, 0.0]
-    got = rewards.accuracy_reward(completions=cs, assistant=["<answer>B.</answer>", "<answer>C</answer>", "<answer>3.14</answer>"])
+    # the dataset's `assistant` column is the answer TURN ({"role", "content"}: grpo_dataset.py:157,181; reward_funcs.py:18)
+    turn = lambda s: {"role": "gpt", "content": s}
+    got = rewards.accuracy_reward(completions=cs, assistant=[turn("<answer>B.</answer>"), turn("<answer>C</answer>"), turn("<answer>3.14</answer>")])
     assert got == [1.0, 0.0, 1.0]
-    assert rewards.accuracy_reward(completions=cs[:1], assistant=["<answer>the long free-form sentence here ok</answer>"]) == [None]
+    assert rewards.accuracy_reward(completions=cs, assistant=["<answer>B</answer>", "<answer>B</answer>", "<answer>3.1</answer>"]) == [1.0, 1.0, 0.0]
+
+
+def test_accuracy_reward_follows_the_reference_dispatch():
+    """reward_funcs.py:17-76 / reward_utils.py:6-68 case by case: no <answer> tag extracts '' (never the whole text), the kind of
+    the ground truth picks the comparison, decimals must be present on both sides or neither, > 3 decimals is a regression
+    target scored 1 - relative error, <= 5 plain words is scored 1 - WER, any exception scores 0 (and is reported)."""
+    comp = lambda s: [{"role": "assistant", "content": s}]
+    turn = lambda s: {"role": "gpt", "content": s}
+    acc = lambda pred, truth: rewards.accuracy_reward(completions=[comp(pred)], assistant=[turn(truth)])[0]
+    assert rewards.extract_answer("B is right") == "" and rewards.extract_answer("<answer>\n B \n</answer>") == "B"
+    assert acc("B is right", "<answer>B</answer>") == 0.0                       # untagged prediction: '' -> no letter
+    assert acc("<answer>(b) because</answer>", "<answer>B</answer>") == 0.0     # letter must lead the answer: '(' does not match
+    assert acc("<answer>b) because</answer>", "<answer>B. the cat</answer>") == 1.0
+    assert rewards.answer_kind("1,234") == "numerical" and rewards.answer_kind("0.12345") == "regression"
+    assert rewards.answer_kind("red car 12") == "OCR" and rewards.answer_kind("the long free form answer of many words, really") == "free-form"
+    assert rewards.answer_kind("a long answer") == "multiple choice"        # the reference's rule: ANY answer that starts with a-e is a letter choice
+    assert acc("<answer>12</answer>", "<answer>12.0</answer>") == 0.0           # decimal presence must match
+    assert acc("<answer>12.004</answer>", "<answer>12.0</answer>") == 1.0       # equal at 2 decimals
+    assert acc("<answer>1,234</answer>", "<answer>1,234</answer>") == 1.0
+    assert acc("<answer>about 3</answer>", "<answer>3</answer>") == 0.0         # whole answer must parse as a number
+    assert abs(acc("<answer>0.5</answer>", "<answer>0.40000</answer>") - 0.75) < 1e-6      # regression: 1 - |0.5-0.4|/0.4
+    assert acc("<answer>red car 12</answer>", "<answer>red car 12</answer>") == 1.0
+    assert abs(acc("<answer>red bus 12</answer>", "<answer>red car 12</answer>") - (1 - 1 / 3)) < 1e-9
+    assert rewards.word_error_rate("a b c", "a c") == pytest.approx(1 / 3)
+    assert acc("<answer>x</answer>", 5) == 0.0                                   # broken column -> exception -> 0.0
+
+
+def test_reward_module_seam_and_sentence_model_passthrough(tmp_path, monkeypatch):
+    """--reward_module points at the USER's module (default: src.train.reward_funcs when importable); the functions of
+    the reference's TAR family are called with sentence_model= (grpo_trainer.py:878-886)"""
+    import sys
+    import types
+    mod = types.ModuleType("user_rewards_for_test")
+    seen = {}
+
+    def temporal_grounding_sentence_embedding_consistency_reward(completions, assistant, temporal_grounding, sentence_model,
+                                                                 buffer_seconds, similarity_threshold, **kwargs):
+        seen.update(sentence_model=sentence_model, buffer_seconds=buffer_seconds, similarity_threshold=similarity_threshold,
+                    question=kwargs["prompts"][0][1]["content"][1]["text"], tg=temporal_grounding[0])
+        return [0.25] * len(completions)
+
+    def plain_reward(completions, **kwargs):
+        assert "sentence_model" not in kwargs
+        return [None] * len(completions)
+    mod.temporal_grounding_sentence_embedding_consistency_reward = temporal_grounding_sentence_embedding_consistency_reward
+    mod.plain_reward = plain_reward
+    monkeypatch.setitem(sys.modules, "user_rewards_for_test", mod)
+    a = params.parse_args(["--reward_module", "user_rewards_for_test", "--reward_func_names",
+                           "temporal_grounding_sentence_embedding_consistency_reward,plain_reward", "--reward_weights", "1.0,1.0",
+                           "--buffer_seconds", "3", "--similarity_threshold", "0.5"])
+    funcs, w, names = rewards.load_reward_funcs(a.reward_module, a)
+    assert names == ["temporal_grounding_sentence_embedding_consistency_reward", "plain_reward"]
+    from video_r2_amd.trainer import call_reward_funcs
+    ex = {"prompt": [{"role": "system", "content": "s"}, {"role": "user", "content": [{"type": "video", "video": "v"}, {"type": "text", "text": "Q?"}]}],
+          "assistant": {"role": "gpt", "content": "<answer>A</answer>"}, "temporal_grounding": {"00:01-00:02": "x"}, "temporal_captions": {}}
+    out = call_reward_funcs(funcs, names, [ex], [["c0", "c1"]], a, sentence_model="SENTINEL")
+    assert out.shape == (2, 2) and out[:, 0].tolist() == [0.25, 0.25] and torch.isnan(out[:, 1]).all()
+    assert seen == {"sentence_model": "SENTINEL", "buffer_seconds": 3, "similarity_threshold": 0.5, "question": "Q?", "tg": {"00:01-00:02": "x"}}
+    # no sentence-transformers offline: selecting a TAR reward without a model must say so, not pass None silently
+    with pytest.raises(RuntimeError, match="sentence-transformers"):
+        rewards.load_sentence_model(names)
+    assert rewards.load_sentence_model(["format_reward"]) is None
+    assert rewards.resolve_reward_module(None) == "video_r2_amd.rewards" and rewards.resolve_reward_module("x.y") == "x.y"
 
 
 @pytest.mark.parametrize("loss_type", ["bnpo", "mapo", "mapo_bnpo", "grpo"])
@@ -125,6 +191,50 @@ def test_oracle_loss_gradient_matches_autograd():
                           epsilon_low=0.2, epsilon_high=0.28, loss_type=lt, max_completion_length=16)
             assert abs(got["loss"] - L.item()) < 1e-6
             np.testing.assert_allclose(got["dloss_dlogp"], t.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_loss_normalisation_unit_emulates_eight_ranks_of_one_completion():
+    """The reference recipe (train_grpo.sh:4-7: 8 ranks x per_device_train_batch_size 1) computes the loss of ONE completion per
+    rank (grpo_trainer.py:1146-1151) and DDP averages the ranks' gradients.  Emulated here with torch autograd: 8 independent
+    single-row losses, mean of them; norm_rows=1 must reproduce value and gradient for every aggregation, `bnpo` then equals
+    the `grpo` aggregation (per-sequence token mean), and the whole-batch token mean (norm_rows=0) differs on ragged lengths."""
+    rng = np.random.default_rng(8)
+    B, C = 8, 12
+    lp = (-1 + rng.standard_normal((B, C))).astype(np.float32)
+    ref = (lp + 0.2 * rng.standard_normal((B, C))).astype(np.float32)
+    lens = np.asarray([12, 3, 1, 7, 12, 5, 9, 2])
+    mask = (np.arange(C)[None] < lens[:, None]).astype(np.int32)
+    adv = rng.standard_normal(B).astype(np.float32)
+    for lt in ("grpo", "bnpo", "dr_grpo"):
+        t = torch.tensor(lp, requires_grad=True)
+        total = 0.0
+        for rnk in range(B):                         # one rank = one completion
+            row, m = t[rnk:rnk + 1], torch.tensor(mask[rnk:rnk + 1]).float()
+            rr = torch.tensor(ref[rnk:rnk + 1])
+            kl = torch.exp(rr - row) - (rr - row) - 1
+            c1 = torch.exp(row - row.detach())
+            A = torch.tensor(adv[rnk:rnk + 1]).unsqueeze(1)
+            ptl = -torch.min(c1 * A, torch.clamp(c1, 0.8, 1.2) * A) + 0.04 * kl
+            if lt == "grpo":
+                L = ((ptl * m).sum(-1) / m.sum(-1).clamp(min=1)).mean()
+            elif lt == "bnpo":
+                L = (ptl * m).sum() / m.sum().clamp(min=1)
+            else:
+                L = (ptl * m).sum() / (1 * 16)
+            total = total + L / B                    # DDP: mean over ranks
+        total.backward()
+        got = og.loss(lp, mask, adv, ref_per_token_logps=ref, beta=0.04, loss_type=lt, max_completion_length=16, norm_rows=1)
+        assert abs(got["loss"] - total.item()) < 1e-6
+        np.testing.assert_allclose(got["dloss_dlogp"], t.grad.numpy(), rtol=1e-4, atol=1e-7)
+    per_rank = og.loss(lp, mask, adv, ref_per_token_logps=ref, beta=0.04, loss_type="bnpo", norm_rows=1)
+    as_grpo = og.loss(lp, mask, adv, ref_per_token_logps=ref, beta=0.04, loss_type="grpo")
+    whole = og.loss(lp, mask, adv, ref_per_token_logps=ref, beta=0.04, loss_type="bnpo")
+    assert abs(per_rank["loss"] - as_grpo["loss"]) < 1e-6
+    np.testing.assert_allclose(per_rank["dloss_dlogp"], as_grpo["dloss_dlogp"], rtol=1e-5, atol=1e-8)
+    assert abs(whole["loss"] - per_rank["loss"]) > 1e-3          # long completions weigh more in the whole-batch token mean
+    # the per-rank metrics are means of per-rank ratios (gather_for_metrics(...).nanmean(), :1159-1177)
+    kl_rows = [og.loss(lp[i:i + 1], mask[i:i + 1], adv[i:i + 1], ref_per_token_logps=ref[i:i + 1], beta=0.04)["kl"] for i in range(B)]
+    assert abs(per_rank["kl"] - np.mean(kl_rows)) < 1e-6
 
 
 def test_tiny_preset_matches_the_fixture_config():

@@ -464,6 +464,32 @@ def test_grpo_loss_kernel(dev, loss_type, with_old):
     assert np.abs(got["dlogp"].cpu().numpy() - want["dloss_dlogp"]).max() < 1e-6
 
 
+@pytest.mark.parametrize("loss_type", ["bnpo", "mapo_bnpo", "grpo", "dr_grpo", "gmpo"])
+@pytest.mark.parametrize("unit", [1, 2, 4])
+def test_grpo_loss_kernel_per_rank_normalisation(dev, loss_type, unit):
+    """norm_rows = the reference's per-rank micro-batch (equal on every rank, so it divides B): ragged lengths, an empty completion"""
+    from oracle import grpo as og
+    from video_r2_amd.host import grpo as hg
+    B, C = 8, 41
+    rng = np.random.default_rng(11 + unit)
+    lp = (-2 + rng.standard_normal((B, C))).astype(np.float32)
+    ref = (lp + 0.3 * rng.standard_normal((B, C))).astype(np.float32)
+    old = (lp + 0.25 * rng.standard_normal((B, C))).astype(np.float32)
+    lens = np.asarray([1, C, 7, 0, 23, 40, 2, 15])
+    mask = (np.arange(C)[None, :] < lens[:, None]).astype(np.int32)
+    adv = rng.standard_normal(B).astype(np.float32)
+    want = og.loss(lp, mask, adv, ref_per_token_logps=ref, old_per_token_logps=old, beta=0.04, epsilon_low=0.2,
+                   epsilon_high=0.28, loss_type=loss_type, max_completion_length=64, norm_rows=unit)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    got = hg.grpo_loss(t(lp), t(mask), t(adv), ref_logps=t(ref), old_logps=t(old), beta=0.04, epsilon_low=0.2,
+                       epsilon_high=0.28, loss_type=loss_type, max_completion_length=64, norm_rows=unit, stream=S())
+    assert abs(got["loss"].item() - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"]))
+    assert abs(got["kl"].item() - want["kl"]) <= 1e-5 * max(1.0, abs(want["kl"]))
+    for k in ("clip_low", "clip_high", "clip_region"):
+        assert abs(got[k].item() - want[k]) < 1e-6
+    assert np.abs(got["dlogp"].cpu().numpy() - want["dloss_dlogp"]).max() < 1e-6
+
+
 @pytest.mark.parametrize("M", [5, 16, 27, 64, 128])
 def test_gemv_fp8_weights_exact_and_random(dev, M):
     """weight-only fp8 decode GEMVs (config 5): e4m3 weights with per-channel scales, bf16 activations.  Exact case: integer

@@ -72,6 +72,45 @@ def test_generate_batch_of_groups_and_scoring_vs_oracle():
         m.generate(input_ids=bad, attention_mask=am, pixel_values_videos=pvt, video_grid_thw=gtt, generation_config=gc)
 
 
+def test_rows_with_equal_ids_but_different_videos_are_not_merged():
+    """video placeholder ids are the same for every clip of one geometry: two samples with the same question template must
+    still be encoded and scored against their OWN clips (rows are copies only if ids, grids and pixel values all agree)"""
+    from video_r2_amd.model import GenerationConfig
+    m, w, ocfg = _model(2, 19)
+    cfg = m.cfg
+    g = torch.Generator().manual_seed(2)
+    pxs = []
+    for _ in range(2):
+        frames = torch.randint(0, 256, (2, 3, 56, 84), generator=g, dtype=torch.uint8).numpy()
+        px, grid = pixels_from_frames(frames, cfg.vision)
+        pxs.append(px)
+    tv = grid[0] * grid[1] * grid[2] // 4
+    p = [21, cfg.vision_start_token_id] + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 30, 31]
+    ids = torch.tensor([p, p, p, p])                                   # rows 0,1: clip A twice; rows 2,3: clip B twice
+    am = torch.ones_like(ids)
+    pvt = torch.from_numpy(np.concatenate([pxs[0], pxs[0], pxs[1], pxs[1]])).cuda()
+    gtt = torch.tensor([grid] * 4)
+    C = 6
+    comp = torch.randint(32, 200, (4, C), generator=g)
+    full = torch.cat([ids, comp], 1)
+    fam = torch.ones_like(full)
+    lp = m.per_token_logps(full, fam, C, temperature=0.9, pixel_values_videos=pvt, video_grid_thw=gtt, second_per_grid_ts=[1.0] * 4)
+    want = om.per_token_logps(w, ocfg, full, fam.numpy(), C, 0.9, pixel_values_videos=pvt.cpu(), video_grid_thw=np.asarray([grid] * 4),
+                              second_per_grid_ts=[1.0] * 4).numpy()
+    r = rel_err(lp.cpu().numpy(), want)
+    assert np.quantile(r, 0.95) < 1e-3 and r.max() < 2e-3, (np.quantile(r, 0.95), r.max())
+    # scoring rows 2,3 against clip A instead (what merging by ids alone did) is visibly different
+    wrong = om.per_token_logps(w, ocfg, full[2:], fam[2:].numpy(), C, 0.9, pixel_values_videos=torch.from_numpy(np.concatenate([pxs[0], pxs[0]])),
+                               video_grid_thw=np.asarray([grid] * 2), second_per_grid_ts=[1.0] * 2).numpy()
+    assert rel_err(wrong, want[2:]).max() > 1e-2
+    out = m.generate(input_ids=ids, attention_mask=am, pixel_values_videos=pvt, video_grid_thw=gtt, second_per_grid_ts=[1.0] * 4,
+                     generation_config=GenerationConfig(max_new_tokens=4, eos_token_id=-1, seed=3))
+    assert out.shape == (4, ids.shape[1] + 4)
+    with pytest.raises(ValueError, match="top-k only"):
+        m.generate(input_ids=ids, attention_mask=am, pixel_values_videos=pvt, video_grid_thw=gtt,
+                   generation_config=GenerationConfig(max_new_tokens=4, top_p=0.9))
+
+
 def test_save_pretrained_roundtrip(tmp_path):
     from video_r2_amd.model import VideoR2Model
     m, w, ocfg = _model(7, 23)

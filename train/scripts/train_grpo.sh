@@ -2,6 +2,17 @@
 # GRPO stage on MI355X.  Entry point and flag names follow the reference recipe so existing launch tooling keeps working;
 # underneath: one process per GPU (torch.distributed.run), replicated weights, prompt groups sharded over the ranks,
 # one RCCL gradient all-reduce per optimiser step.  Every flag can be overridden by appending it ("$@" wins).
+#
+# Batch shape: the batch flags count completions per device as in the reference, but a prompt group (num_generations
+# completions) never leaves its GPU, so one optimiser step takes max(1, per_device_train_batch_size *
+# gradient_accumulation_steps / num_generations) prompts PER RANK: with the recipe values below that is 8 prompts per step on
+# 8 GPUs where the reference takes 1 (8x fewer steps per epoch at the same learning rate); NUM_DEVICES=1 reproduces the
+# reference's one prompt per step.  Raise per_device_train_batch_size to num_generations * P to decode P groups per GPU
+# together (the decode streams the weights once for up to 128 sequences).
+#
+# Rewards: the functions are looked up by name in --reward_module (default: your src/train/reward_funcs.py next to this
+# entry point if it imports, else the engine's built-in accuracy / format rewards).  The temporal-grounding reward named
+# below is the reference's own code (LLM judge + MiniLM): keep your reward_funcs.py in place, or drop the name.
 set -euo pipefail
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0                       # dmabuf IPC for RCCL on this driver
@@ -46,8 +57,8 @@ grpo_flags=(
     --max_prompt_length 32768
     --max_completion_length 1024
     --beta 0.04
-    --reward_func_names "accuracy_reward,format_reward"
-    --reward_weights 1.0,1.0
+    --reward_func_names "accuracy_reward,format_reward,temporal_grounding_sentence_embedding_consistency_reward"
+    --reward_weights 1.0,1.0,1.0
     --reward_llm_judge ''
     --similarity_threshold 0.75
     --buffer_seconds 2

@@ -2,48 +2,149 @@
 
     torchrun --nproc-per-node=N src/train/train_grpo.py --model_id <HF dir> --data_path <json> ... (train/scripts/train_grpo.sh)
 
-Loads an HF Qwen2_5_VLForConditionalGeneration checkpoint directory (safetensors + config.json), builds the reward
-functions by name, shards prompt groups over ranks and runs the rollout / scoring / loss loop.  The tokenizer / chat
-template / video decode front end is the caller's ``processing_fn`` (host Python, out of GPU scope); without one the
-script stops after loading, which is what the offline CI exercises.
+What the reference's train() does (/root/reference/train/src/train/train_grpo.py:67-208), step for step:
+  parse flags -> load the HF Qwen2_5_VLForConditionalGeneration checkpoint directory (safetensors + config.json) -> dataset
+  (video_r2_amd/host/dataset.py) -> reward functions by name from the user's module -> trainer -> train, resuming from the newest
+  output_dir/checkpoint-* when there is one (:184-187) -> save the final weights in HF layout (:208).
+--save_strategy steps / --save_steps / --save_total_limit behave as HF Trainer's: checkpoint-<step> directories with the
+weights (loadable by eval/lmms-eval and demo/ as they are) + optimiser / trainer state, oldest ones pruned.  The frozen KL
+reference is always built from --model_id (the SFT model), also on resume.  Sampling seeds are a pure function of
+(seed, step, rank) and the prompt order of (seed, epoch), so a resumed run continues the same random streams without
+stored RNG state.  The host front end (video decode, frame sampling, overlays, chat template, tokeniser:
+video_r2_amd/host/frontend.py) runs --dataloader_num_workers threads one step ahead of the GPU.
 """
 import os
+import re
+import shutil
 import sys
+import time
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+TRAIN_DIR = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))     # so that `src.train.reward_funcs` resolves
+for p_ in (ROOT, TRAIN_DIR):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
+
+
+def checkpoints(output_dir):
+    """[(step, path)] of output_dir/checkpoint-<step>, oldest first."""
+    out = []
+    if os.path.isdir(output_dir):
+        for name in os.listdir(output_dir):
+            m = re.fullmatch(r"checkpoint-(\d+)", name)
+            if m and os.path.exists(os.path.join(output_dir, name, "trainer_state.pt")):
+                out.append((int(m.group(1)), os.path.join(output_dir, name)))
+    return sorted(out)
+
+
+def prune_checkpoints(output_dir, keep):
+    if keep is None or keep <= 0:
+        return
+    for _, path in checkpoints(output_dir)[:-keep]:
+        shutil.rmtree(path, ignore_errors=True)
+
+
+PROCESSOR_FILES = ("tokenizer.json", "tokenizer_config.json", "vocab.json", "merges.txt", "added_tokens.json", "special_tokens_map.json",
+                   "preprocessor_config.json", "video_preprocessor_config.json", "chat_template.json", "chat_template.jinja",
+                   "generation_config.json")
+
+
+def copy_processor_files(model_dir, out_dir):
+    """tokeniser / processor / generation configs travel with the weights, so a saved directory loads wherever the input did"""
+    if not os.path.isdir(str(model_dir)):
+        return
+    os.makedirs(out_dir, exist_ok=True)
+    for name in PROCESSOR_FILES:
+        src = os.path.join(model_dir, name)
+        if os.path.exists(src) and not os.path.exists(os.path.join(out_dir, name)):
+            shutil.copy2(src, os.path.join(out_dir, name))
+
+
+def prefetched(steps, processing_fn, workers):
+    """(examples, processed) per step; with workers > 0 the host front end of step i + 1 runs on a thread pool while the GPU
+    works on step i (decode libraries and PIL release the GIL; frames come back in pinned memory)."""
+    if workers <= 0:
+        for ex in steps:
+            yield ex, [processing_fn(e) for e in ex]
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vr2-frontend") as pool:
+        it = iter(steps)
+        cur = next(it, None)
+        futs = [pool.submit(processing_fn, e) for e in cur] if cur is not None else None
+        while cur is not None:
+            nxt = next(it, None)
+            nfuts = [pool.submit(processing_fn, e) for e in nxt] if nxt is not None else None
+            yield cur, [f.result() for f in futs]
+            cur, futs = nxt, nfuts
 
 
 def train(argv=None, processing_fn=None, dataset=None):
     import torch
     from video_r2_amd import dist as vdist
     from video_r2_amd import params, rewards
+    from video_r2_amd.host import dataset as hd
+    from video_r2_amd.host import frontend as hfe
     from video_r2_amd.model import VideoR2Model
     from video_r2_amd.trainer import QwenGRPOTrainer
 
     args = params.parse_args(argv)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
     rank, world = vdist.init(device=device)
-    if rank == 0 and args.ignored:
-        print(f"[train_grpo] flags accepted and ignored by the MI355X engine: {sorted(args.ignored)}", file=sys.stderr)
+    log = (lambda *a: print("[train_grpo]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+    if args.ignored:
+        log(f"flags accepted and ignored by the MI355X engine: {sorted(args.ignored)}")
+    if not args.freeze_vision_tower or not args.freeze_merger:
+        log("note: the vision tower and the merger stay frozen in this engine (the shipped recipe freezes both)")
     model = VideoR2Model.from_pretrained(args.model_id, device=device)
-    funcs, weights, names = rewards.load_reward_funcs("video_r2_amd.rewards", args)
-    if dataset is None or processing_fn is None:
-        if rank == 0:
-            print("[train_grpo] model and reward functions loaded; no dataset/processing_fn given, nothing to train", file=sys.stderr)
-        return model
-    trainer = QwenGRPOTrainer(model, funcs, args, dataset, processing_fn, reward_weights=weights, reward_func_names=names)
-    for step, examples in enumerate(trainer.iter_steps()):
-        out = trainer.step(examples)
-        if rank == 0 and (step + 1) % args.logging_steps == 0:
-            print({"step": step + 1, **trainer.log()})
-        if args.max_steps > 0 and step + 1 >= args.max_steps:
+    if dataset is None:
+        if not args.data_path:
+            raise ValueError("--data_path is required")
+        dataset = hd.make_grpo_data_module(args.model_id, None, args)["train_dataset"]
+    if processing_fn is None:
+        tok = hfe.load_tokenizer(args.model_id if os.path.isdir(str(args.model_id)) else None, model.cfg)
+        log(f"tokeniser: {type(tok).__name__}; video front end on {max(0, args.dataloader_num_workers)} prefetch thread(s)")
+        processing_fn = hfe.ProcessingFrontEnd(model.cfg, tok)
+    module = rewards.resolve_reward_module(args.reward_module)
+    funcs, weights, names = rewards.load_reward_funcs(module, args)
+    log(f"reward functions {names} (weights {weights}) from {module}")
+    sentence_model = rewards.load_sentence_model(names, args.sentence_model_name)
+    trainer = QwenGRPOTrainer(model, funcs, args, dataset, processing_fn, reward_weights=weights, reward_func_names=names,
+                              sentence_model=sentence_model)
+    resume = args.resume_from_checkpoint or (checkpoints(args.output_dir)[-1][1] if checkpoints(args.output_dir) else "")
+    if resume:
+        trainer.load_checkpoint(resume)
+        log(f"resumed from {resume} at step {trainer.global_step}")
+    log(f"{trainer.total_steps} optimiser steps, {trainer.groups_per_step} prompt groups x {args.num_generations} completions each")
+    save_every = args.save_steps if (args.save_strategy == "steps" and args.save_steps > 0) else 0
+    t0 = time.time()
+    for examples, processed in prefetched(trainer.iter_steps(), processing_fn, args.dataloader_num_workers):
+        if trainer.global_step >= trainer.total_steps:
             break
+        trainer.step(examples, processed)
+        step = trainer.global_step
+        if rank == 0 and (step % max(1, args.logging_steps) == 0 or step == trainer.total_steps):
+            print({"step": step, "epoch": round(step / max(1, trainer.steps_per_epoch * max(1, args.num_iterations)), 4),
+                   "elapsed_s": round(time.time() - t0, 1), **trainer.log()}, flush=True)
+        if save_every and step % save_every == 0:
+            if rank == 0:                                   # replicas are bit-identical: one writer
+                path = trainer.save_checkpoint(args.output_dir)
+                copy_processor_files(args.model_id, path)
+                prune_checkpoints(args.output_dir, args.save_total_limit)
+                log(f"saved {path}")
+            if world > 1:
+                import torch.distributed as dist
+                dist.barrier()
     if rank == 0:
         model.save_pretrained(args.output_dir)
+        copy_processor_files(args.model_id, args.output_dir)
+        log(f"final weights in {args.output_dir}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return model
 
 

@@ -282,16 +282,24 @@ __global__ __launch_bounds__(256) void lse_gather_kernel(const float* __restrict
 }
 
 // loss types: 0 grpo, 1 bnpo, 2 dr_grpo, 3 gmpo, 4 mapo (= grpo aggregation), 5 mapo_bnpo (= bnpo aggregation)
+// unit = rows per normalisation block of the token-mean aggregations (bnpo, mapo_bnpo) and of the kl / clip metrics: the
+// reference computes them over ONE RANK's micro-batch (per_device_train_batch_size completions, 1 in train_grpo.sh) and then
+// averages over ranks and accumulation steps (grpo_trainer.py:1148-1149, :1159-1177 + DDP / Trainer means); here a rank owns
+// whole groups, so the B rows are cut into blocks of `unit` consecutive rows, each normalised by its own token count, and the
+// blocks are averaged (blocks without tokens count as 0 in the loss, as clamp(min=1) does, and are skipped in the metrics,
+// as nanmean does).  unit <= 0 or >= B: one block = the whole batch.
 __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* __restrict__ lp, const float* __restrict__ ref,
                                                         const float* __restrict__ old, const int* __restrict__ mask,
                                                         const float* __restrict__ adv, int B, int C, float beta, float eps_lo,
-                                                        float eps_hi, int loss_type, float max_completion_length,
+                                                        float eps_hi, int loss_type, float max_completion_length, int unit,
                                                         float* __restrict__ out /*[8]*/, float* __restrict__ dlogp) {
   __shared__ float scratch[4];
-  __shared__ float cnt_s[256], seq_s[256], rowsum_s[256], gsum_s[256];
+  __shared__ float cnt_s[256], raw_s[256], seq_s[256], gsum_s[256], blk_s[256], kl_s[256], low_s[256], high_s[256], reg_s[256];
   const int tid = threadIdx.x;
   const bool gm = loss_type == 3;
   const bool per_seq = (loss_type == 0 || loss_type == 3 || loss_type == 4);
+  if (unit <= 0 || unit > B) unit = B;
+  const int nblk = (B + unit - 1) / unit;
   // per-row token counts (and GMPO sequence log-ratio)
   for (int b = 0; b < B; ++b) {
     float c = 0.f, d = 0.f;
@@ -302,22 +310,21 @@ __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* __restrict_
     }
     c = block_sum_256(c, scratch);
     d = block_sum_256(d, scratch);
-    if (tid == 0) { cnt_s[b] = fmaxf(c, 1.0f); seq_s[b] = d / fmaxf(c, 1.0f); }
+    if (tid == 0) { raw_s[b] = c; cnt_s[b] = fmaxf(c, 1.0f); seq_s[b] = d / fmaxf(c, 1.0f); }
   }
   __syncthreads();
-  float tot_mask = 0.f;
-  for (int b = 0; b < B; ++b) {
+  if (tid < nblk) {                                  // token count of every block
     float c = 0.f;
-    for (int t = tid; t < C; t += 256) c += (float)mask[(long)b * C + t];
-    tot_mask += c;
+    for (int b = tid * unit; b < B && b < (tid + 1) * unit; ++b) c += raw_s[b];
+    blk_s[tid] = c;
   }
-  tot_mask = block_sum_256(tot_mask, scratch);
-  const float tot_clamped = fmaxf(tot_mask, 1.0f);
+  __syncthreads();
   const float lo = 1.0f - eps_lo, hi = 1.0f + eps_hi;
-  float loss_acc = 0.f, kl_acc = 0.f, low_acc = 0.f, high_acc = 0.f, reg_acc = 0.f;
+  float loss_acc = 0.f, tot_mask = 0.f;
   for (int b = 0; b < B; ++b) {
     const float A = adv[b];
-    float rs = 0.f, gs = 0.f;
+    const float blk = fmaxf(blk_s[b / unit], 1.0f);
+    float gs = 0.f, kl_acc = 0.f, low_acc = 0.f, high_acc = 0.f, reg_acc = 0.f;
     for (int t = tid; t < C; t += 256) {
       const long i = (long)b * C + t;
       const float mk = (float)mask[i];
@@ -341,9 +348,8 @@ __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* __restrict_
       float wgt;
       if (per_seq) wgt = mk / cnt_s[b] / (float)B;
       else if (loss_type == 2) wgt = mk / ((float)B * max_completion_length);
-      else wgt = mk / tot_clamped;
+      else wgt = mk / blk / (float)nblk;
       loss_acc += ptl * wgt;
-      rs += ptl * mk;
       kl_acc += kl * mk;
       const float isl = (coef1 < lo && A < 0.f) ? 1.f : 0.f;
       const float ish = (coef1 > hi && A > 0.f) ? 1.f : 0.f;
@@ -353,11 +359,12 @@ __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* __restrict_
         else dlogp[i] = wgt * (dptl_dc1 * coef1 + beta * dkl);
       }
     }
-    if (gm && dlogp) {
-      gs = block_sum_256(gs, scratch);
-      if (tid == 0) gsum_s[b] = gs;
-    }
-    (void)rs; (void)rowsum_s;
+    if (gm && dlogp) gs = block_sum_256(gs, scratch);
+    kl_acc = block_sum_256(kl_acc, scratch);
+    low_acc = block_sum_256(low_acc, scratch);
+    high_acc = block_sum_256(high_acc, scratch);
+    reg_acc = block_sum_256(reg_acc, scratch);
+    if (tid == 0) { gsum_s[b] = gs; kl_s[b] = kl_acc; low_s[b] = low_acc; high_s[b] = high_acc; reg_s[b] = reg_acc; tot_mask += raw_s[b]; }
   }
   __syncthreads();
   if (gm && dlogp) {
@@ -370,16 +377,20 @@ __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* __restrict_
     }
   }
   loss_acc = block_sum_256(loss_acc, scratch);
-  kl_acc = block_sum_256(kl_acc, scratch);
-  low_acc = block_sum_256(low_acc, scratch);
-  high_acc = block_sum_256(high_acc, scratch);
-  reg_acc = block_sum_256(reg_acc, scratch);
   if (tid == 0) {
+    // metrics: mean over the blocks that have tokens of (masked sum / token count)
+    float kl = 0.f, low = 0.f, high = 0.f, reg = 0.f, live = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+      if (blk_s[k] <= 0.f) continue;
+      float a = 0.f, l = 0.f, h = 0.f, r = 0.f;
+      for (int b = k * unit; b < B && b < (k + 1) * unit; ++b) { a += kl_s[b]; l += low_s[b]; h += high_s[b]; r += reg_s[b]; }
+      kl += a / blk_s[k]; low += l / blk_s[k]; high += h / blk_s[k]; reg += r / blk_s[k]; live += 1.f;
+    }
     out[0] = loss_acc;
-    out[1] = kl_acc / tot_mask;
-    out[2] = low_acc / tot_mask;
-    out[3] = high_acc / tot_mask;
-    out[4] = reg_acc / tot_mask;
+    out[1] = kl / live;                              // 0/0 = NaN when no block has tokens, as the reference's nanmean of nothing
+    out[2] = low / live;
+    out[3] = high / live;
+    out[4] = reg / live;
     out[5] = tot_mask;
   }
 }
@@ -423,13 +434,14 @@ extern "C" int vr2_lse_gather(const void* logits_f32, int64_t ldl, int64_t R, in
 
 extern "C" int vr2_grpo_loss(const void* logp_f32, const void* ref_logp_f32, const void* old_logp_f32, const void* mask_i32,
                              const void* adv_f32, int64_t B, int64_t C, float beta, float eps_low, float eps_high,
-                             int loss_type, float max_completion_length, void* out8_f32, void* dlogp_f32, void* stream) {
+                             int loss_type, float max_completion_length, int64_t norm_rows, void* out8_f32, void* dlogp_f32,
+                             void* stream) {
   VR2_REQUIRE(B >= 1 && B <= 256 && C >= 1, "vr2_grpo_loss: B=%ld must be in [1,256]", (long)B);
   VR2_REQUIRE(loss_type >= 0 && loss_type <= 5, "vr2_grpo_loss: unknown loss type %d", loss_type);
   VR2_REQUIRE(beta == 0.f || ref_logp_f32 != nullptr, "vr2_grpo_loss: beta != 0 needs reference log-probs");
   hipLaunchKernelGGL(grpo_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)logp_f32,
                      (const float*)ref_logp_f32, (const float*)old_logp_f32, (const int*)mask_i32, (const float*)adv_f32,
-                     (int)B, (int)C, beta, eps_low, eps_high, loss_type, max_completion_length, (float*)out8_f32,
-                     (float*)dlogp_f32);
+                     (int)B, (int)C, beta, eps_low, eps_high, loss_type, max_completion_length, (int)norm_rows,
+                     (float*)out8_f32, (float*)dlogp_f32);
   return vr2_check_launch("vr2_grpo_loss");
 }

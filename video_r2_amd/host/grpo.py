@@ -61,8 +61,10 @@ def group_advantages(rewards_per_func, reward_weights, num_generations, loss_typ
 
 
 def grpo_loss(logps, completion_mask_i32, advantages, *, ref_logps=None, old_logps=None, beta=0.04, epsilon_low=0.2,
-              epsilon_high=0.2, loss_type="bnpo", max_completion_length=None, stream=0, want_grad=True):
-    """Device tensors in, device tensors out: dict(loss, kl, clip_low, clip_high, clip_region, n_tokens [0-d], dlogp [B,C])."""
+              epsilon_high=0.2, loss_type="bnpo", max_completion_length=None, norm_rows=0, stream=0, want_grad=True):
+    """Device tensors in, device tensors out: dict(loss, kl, clip_low, clip_high, clip_region, n_tokens [0-d], dlogp [B,C]).
+    norm_rows: rows per normalisation block of bnpo / mapo_bnpo and of the kl / clip metrics (the reference's per-rank
+    micro-batch, per_device_train_batch_size completions); 0 = the whole batch."""
     if loss_type not in LOSS_TYPES:
         raise ValueError(f"Unknown loss type: {loss_type}")
     B, C = logps.shape
@@ -73,6 +75,6 @@ def grpo_loss(logps, completion_mask_i32, advantages, *, ref_logps=None, old_log
     lib.call("vr2_grpo_loss", logps.contiguous(), None if ref_logps is None else ref_logps.contiguous(),
              None if old_logps is None else old_logps.contiguous(), completion_mask_i32.to(torch.int32).contiguous(),
              advantages.to(torch.float32).contiguous(), B, C, float(beta), float(epsilon_low), float(epsilon_high),
-             LOSS_TYPES[loss_type], mcl, out, grad, stream)
+             LOSS_TYPES[loss_type], mcl, int(norm_rows), out, grad, stream)
     return dict(loss=out[0], kl=out[1] if beta != 0.0 else None, clip_low=out[2], clip_high=out[3], clip_region=out[4],
                 n_tokens=out[5], dlogp=grad)

@@ -36,17 +36,19 @@ class GenerationConfig:
     seed: int = 0
 
 
-def _groups(ids, mask):
-    """Consecutive identical (unpadded) rows -> [(first_row, n_rows, unpadded_ids)]."""
+def _groups(ids, mask, same_video=None):
+    """Consecutive rows with identical unpadded ids AND identical video inputs -> [(first_row, n_rows, unpadded_ids)].
+    same_video(b) says whether row b carries the same clips (grids and pixel values) as row b - 1: video placeholder ids
+    are the same for every clip of one geometry, so equal ids alone do not make two rows copies of one sample."""
     out = []
     prev = None
     for b in range(ids.shape[0]):
         row = ids[b][mask[b].astype(bool)]
-        if prev is not None and row.shape == prev.shape and np.array_equal(row, prev):
+        if prev is not None and row.shape == prev.shape and np.array_equal(row, prev) and (same_video is None or same_video(b)):
             out[-1][1] += 1
         else:
             out.append([b, 1, row])
-            prev = row
+        prev = row
     return out
 
 
@@ -96,6 +98,30 @@ class VideoR2Model:
         offs = np.concatenate([[0], np.cumsum(sizes)])
         return g, offs
 
+    def _same_video_fn(self, ids, mask, pixel_values_videos, grids, offs):
+        """-> same_video(b) for _groups: row b's clips (consumed in order, as many as its video tokens need) equal row b-1's."""
+        if grids is None or pixel_values_videos is None:
+            return None
+        unit = self.cfg.vision.spatial_merge_size ** 2
+        spans, cur = [], 0
+        for b in range(ids.shape[0]):
+            need = int(((ids[b] == self.cfg.video_token_id) & mask[b].astype(bool)).sum())
+            first, tok = cur, 0
+            while tok < need and cur < len(grids):
+                tok += int(grids[cur][0] * grids[cur][1] * grids[cur][2]) // unit
+                cur += 1
+            spans.append((first, cur))
+        px = pixel_values_videos
+
+        def same(b):
+            (a0, a1), (b0, b1) = spans[b - 1], spans[b]
+            if a1 - a0 != b1 - b0 or not np.array_equal(grids[a0:a1], grids[b0:b1]):
+                return False
+            if a1 == a0:
+                return True
+            return bool(torch.equal(px[int(offs[a0]):int(offs[a1])], px[int(offs[b0]):int(offs[b1])]))
+        return same
+
     def _encode_group(self, row, ids_row, pixel_values_videos, grids, offs, second_per_grid_ts, vid_cursor):
         cfg = self.cfg
         n_vid_tok = int((ids_row == cfg.video_token_id).sum())
@@ -130,7 +156,9 @@ class VideoR2Model:
         pad = cfg.pad_token_id if gc.pad_token_id is None else gc.pad_token_id
         outs = []
         vid_cursor = 0
-        groups = list(_groups(ids, mask))
+        groups = list(_groups(ids, mask, self._same_video_fn(ids, mask, pixel_values_videos, grids, offs)))
+        if gc.top_p not in (None, 1.0):
+            raise ValueError(f"generation_config.top_p={gc.top_p}: the engine's sampler implements temperature + top-k only")
         temp = gc.temperature if gc.do_sample else 1.0
         topk = gc.top_k if gc.do_sample else 1
         eos = gc.eos_token_id if gc.eos_token_id is not None else cfg.eos_token_id
@@ -199,7 +227,7 @@ class VideoR2Model:
         grids, offs = (vs if vs is not None else (None, None))
         out = torch.zeros((B, C), dtype=torch.float32, device=self.device)
         vid_cursor = 0
-        for gi, (row, n, ids_row) in enumerate(_groups(ids[:, :P], mask[:, :P])):
+        for gi, (row, n, ids_row) in enumerate(_groups(ids[:, :P], mask[:, :P], self._same_video_fn(ids[:, :P], mask[:, :P], pixel_values_videos, grids, offs))):
             emb, plan, sec, vid_cursor = self._encode_group(row, ids_row, pixel_values_videos, grids, offs, second_per_grid_ts, vid_cursor)
             for r in range(1, n):
                 _, _, _, vid_cursor = self._skip(ids_row, grids, vid_cursor)

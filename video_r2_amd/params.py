@@ -25,9 +25,15 @@ class GRPOArguments:
     image_folder: Optional[str] = None
     video_subtitles_folder: Optional[str] = None
     output_dir: str = "output"
+    image_min_pixels: int = 3136
+    image_max_pixels: int = 12845056
     video_min_pixels: int = 100352
     video_max_pixels: int = 602112
-    fps: float = 2.0
+    image_resized_width: Optional[int] = None
+    image_resized_height: Optional[int] = None
+    video_resized_width: Optional[int] = None
+    video_resized_height: Optional[int] = None
+    fps: float = 1.0                  # DataArguments default (params.py:218); train_grpo.sh passes 2.0
     # freezing (train_grpo.sh:47-49)
     freeze_vision_tower: bool = False
     freeze_llm: bool = False
@@ -52,6 +58,8 @@ class GRPOArguments:
     temperature: float = 0.9
     top_p: float = 1.0
     top_k: int = 50
+    min_p: Optional[float] = None
+    repetition_penalty: float = 1.0
     seed: int = 42
     shuffle_dataset: bool = True
     # rewards
@@ -62,6 +70,9 @@ class GRPOArguments:
     length_reinforcement_buffer: int = 100
     buffer_seconds: int = 2
     similarity_threshold: float = 0.75
+    reward_module: str = ""           # module holding the *_reward functions; "" = src.train.reward_funcs if importable, else the built-in one
+    sentence_model_name: str = "all-MiniLM-L6-v2"   # embedding model handed to the TAR rewards (grpo_trainer.py:387)
+    log_completions: bool = False
     # optimiser
     learning_rate: float = 1e-6
     weight_decay: float = 0.01
@@ -79,7 +90,11 @@ class GRPOArguments:
     report_to: str = "none"
     dataloader_num_workers: int = 0
     remove_unused_columns: bool = False
+    resume_from_checkpoint: str = ""  # "" = resume from the newest output_dir/checkpoint-* if there is one (train_grpo.py:184-187)
     # engine options without a counterpart in the reference
+    loss_norm_unit: str = "per_device_batch"   # token-mean losses (bnpo, mapo_bnpo) + kl / clip metrics are normalised over blocks of
+                                      # per_device_train_batch_size completions and averaged, as the reference's ranks do;
+                                      # "rank": over all completions a rank holds (round-1 behaviour of this engine)
     decode_weights: str = "bf16"     # "fp8": rollout decode streams per-channel e4m3 weight copies (up to 64 sequences per pass)
     async_rewards: bool = True        # reward functions run on a background thread behind the reference-model scoring
     ignored: dict = field(default_factory=dict)
@@ -102,6 +117,10 @@ def parse_args(argv=None) -> GRPOArguments:
             p.add_argument(f"--{f.name}", type=int, default=default)
         elif isinstance(default, float):
             p.add_argument(f"--{f.name}", type=float, default=default)
+        elif default is None and "int" in str(f.type):
+            p.add_argument(f"--{f.name}", type=lambda v: None if v in ("None", "") else int(v), default=None)
+        elif default is None and "float" in str(f.type):
+            p.add_argument(f"--{f.name}", type=lambda v: None if v in ("None", "") else float(v), default=None)
         else:
             p.add_argument(f"--{f.name}", type=str, default=default)
     for name in IGNORED_FLAGS:
@@ -125,6 +144,8 @@ def parse_args(argv=None) -> GRPOArguments:
         d["epsilon_high"] = float(d["epsilon_high"])
     a = GRPOArguments(**d)
     a.ignored = {k: v for k, v in ignored.items() if v is not None}
+    if a.loss_norm_unit not in ("per_device_batch", "rank"):
+        raise ValueError(f"--loss_norm_unit must be per_device_batch or rank, got {a.loss_norm_unit}")
     if a.num_generations < 2:
         raise ValueError("GRPO requires at least 2 generations per prompt to calculate the advantages.")
     return a

@@ -24,13 +24,43 @@ from .train import Trainer as UpdateEngine
 from .train import cosine_lr
 
 
+def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_example, args, sentence_model=None):
+    """The reward loop of the reference (grpo_trainer.py:846-892) for whole prompt groups: one row per completion, in group
+    order.  Every dataset column except "prompt" / "completion" is repeated per completion and forwarded, plus the three knobs
+    of :871-875; the TAR family additionally gets sentence_model= (:878-886).  None -> NaN.  -> fp32 [rows, n_funcs] (CPU)."""
+    from .rewards import SENTENCE_MODEL_REWARDS
+    prompts, completions, cols = [], [], defaultdict(list)
+    for ex, texts in zip(examples, texts_per_example):
+        for text in texts:
+            prompts.append(ex.get("prompt"))
+            completions.append([{"role": "assistant", "content": text}])
+            for k, v in ex.items():
+                if k not in ("prompt", "completion"):
+                    cols[k].append(v)
+    kw = dict(cols)
+    kw.update(length_reinforcement_buffer=args.length_reinforcement_buffer, buffer_seconds=args.buffer_seconds,
+              similarity_threshold=args.similarity_threshold)
+    out = torch.zeros(len(prompts), len(reward_funcs))
+    for i, (fn, name) in enumerate(zip(reward_funcs, reward_func_names)):
+        extra = {"sentence_model": sentence_model} if name in SENTENCE_MODEL_REWARDS else {}
+        vals = fn(prompts=prompts, completions=completions, **extra, **kw)
+        out[:, i] = torch.tensor([float("nan") if v is None else float(v) for v in vals], dtype=torch.float32)
+    if len(prompts) and torch.isnan(out).all(dim=1).any():
+        row = int(torch.isnan(out).all(dim=1).nonzero()[0, 0])
+        import warnings
+        warnings.warn(f"All reward functions returned None for prompt {prompts[row]!r} / completion {completions[row]!r}. "
+                      "Please ensure that at least one reward function returns a valid reward.")
+    return out
+
+
 class QwenGRPOTrainer:
     def __init__(self, model: VideoR2Model, reward_funcs, args, train_dataset, processing_fn, reward_weights=None,
-                 reward_func_names=None, ref_params=None):
-        """processing_fn(example) -> dict(input_ids 1-D int array (unpadded prompt), pixel_values_videos, video_grid_thw
-        (or video_frames_u8: the resized uint8 frames, normalised + patchified on the device instead),
-        second_per_grid_ts, decode(completion_ids)->str): the host front end (chat template, frame sampling, resize,
-        patchify) stays Python exactly as in the reference (grpo_trainer.py:755-767)."""
+                 reward_func_names=None, ref_params=None, sentence_model=None):
+        """processing_fn(example) -> dict(input_ids 1-D int array (unpadded prompt), second_per_grid_ts,
+        decode(completion_ids) -> list[str], and the clip(s) as ONE of: videos = [(uint8 frames [n,3,H,W], (H', W'))] (resize
+        + normalise + patchify on the device: host/frontend.py ProcessingFrontEnd), video_frames_u8 (already resized),
+        or pixel_values_videos + video_grid_thw (host-processed, as the HF processor returns them)).
+        The host front end (chat template, frame sampling, overlays) stays Python as in the reference (grpo_trainer.py:755-767)."""
         self.model = model
         self.args = args
         self.reward_funcs = list(reward_funcs)
@@ -46,14 +76,40 @@ class QwenGRPOTrainer:
         self._metrics = {"train": defaultdict(list), "eval": defaultdict(list)}
         self.global_step = 0
         self.num_input_tokens_seen = 0
+        self.sentence_model = sentence_model
+        for flag, neutral in (("top_p", 1.0), ("min_p", None), ("repetition_penalty", 1.0)):
+            if getattr(args, flag, neutral) not in (neutral, None if neutral is None else float(neutral)):
+                raise ValueError(f"--{flag} {getattr(args, flag)}: the engine's sampler implements temperature + top-k only "
+                                 f"(the reference recipe leaves {flag} at {neutral}); refusing to ignore it silently")
         self.reducer = vdist.MetricsReducer(device=model.device if vdist.world_size() > 1 and torch.cuda.is_available() else "cpu")
         world = vdist.world_size()
-        eff = args.per_device_train_batch_size * world * args.gradient_accumulation_steps
-        # the reference counts completions per device; here a device owns whole groups: the per-step global number of
-        # prompt groups is eff * G / G = eff  ... and must split evenly over ranks (grpo_trainer.py:524-540 analogue)
-        self.groups_per_step = eff
-        if self.groups_per_step % world:
-            raise ValueError(f"prompt groups per step ({self.groups_per_step}) must be divisible by the world size ({world})")
+        G = self.num_generations
+        # The batch flags count COMPLETIONS per device, as in the reference: per optimiser step a rank works on
+        # per_device_train_batch_size x gradient_accumulation_steps completions (grpo_trainer.py:667-675).  Here a rank owns
+        # whole prompt groups, so that is max(1, .. // G) groups per rank and `world` times as many per step.  With the shipped
+        # recipe (1 x 1 on 8 ranks) the reference spreads ONE prompt over the 8 ranks; whole-group data parallelism cannot go
+        # below one prompt per rank, i.e. 8 prompts (64 completions) per optimiser step, 8x fewer steps per epoch -- said once
+        # on rank 0.  A single GPU reproduces the reference's one prompt per step exactly.
+        per_rank_completions = args.per_device_train_batch_size * args.gradient_accumulation_steps
+        self.groups_per_rank = max(1, per_rank_completions // G)
+        self.groups_per_step = self.groups_per_rank * world
+        ref_prompts = max(1, per_rank_completions * world // G)
+        if vdist.rank() == 0 and (self.groups_per_step != ref_prompts or per_rank_completions % G not in (0, per_rank_completions)):
+            import sys
+            print(f"[QwenGRPOTrainer] {self.groups_per_step} prompt groups ({self.groups_per_step * G} completions) per optimiser step: "
+                  f"{self.groups_per_rank} per rank on {world} rank(s); the reference would take {ref_prompts} prompt(s) per step with these "
+                  "flags (whole groups stay on one GPU here)", file=sys.stderr)
+        # normalisation unit of the token-mean losses / metrics (see vr2_grpo_loss): the reference's per-rank micro-batch
+        pdb = args.per_device_train_batch_size
+        self.norm_rows = 0
+        self.block_groups = 1
+        if getattr(args, "loss_norm_unit", "per_device_batch") == "per_device_batch":
+            if pdb < G:
+                if G % pdb:
+                    raise ValueError(f"per_device_train_batch_size ({pdb}) must divide num_generations ({G}) or be a multiple of it")
+                self.norm_rows = pdb
+            else:
+                self.block_groups = min(max(1, pdb // G), self.groups_per_rank)   # one micro-batch spans this many groups
         self.sampler = RepeatSampler(train_dataset, mini_repeat_count=self.num_generations, batch_size=self.groups_per_step,
                                      repeat_count=args.num_iterations, shuffle=args.shuffle_dataset, seed=args.seed)
         self._buffered = None
@@ -63,14 +119,30 @@ class QwenGRPOTrainer:
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
         self.update = not getattr(args, "freeze_llm", False)
         self.updater = UpdateEngine(model.engine, model.text) if self.update else None
-        n_steps = (len(train_dataset) // self.groups_per_step) * max(1, int(args.num_train_epochs))
+        self.steps_per_epoch = len(train_dataset) // self.groups_per_step
+        n_steps = int(self.steps_per_epoch * float(args.num_train_epochs)) * max(1, args.num_iterations)
         self.total_steps = args.max_steps if args.max_steps > 0 else max(1, n_steps)
+        self._textual_logs = []
 
     # ------------------------------------------------------------------ rollout + scoring for this rank's prompt groups
     MAX_DECODE_ROWS = 128      # sequences per decode weight pass (Engine.decode): G * groups-per-chunk stays below it
 
     def _encode(self, pi):
         eng = self.model.engine
+        vids = pi.get("videos")
+        if vids:
+            if len(vids) == 1:                       # one clip: resize + rescale + normalise + patchify + gather on the device
+                frames, dims = vids[0]
+                emb, plan, _ = eng.encode_frames(frames, resize_to=dims)
+                return emb, plan
+            from .host import processor as hp        # several clips in one prompt: device resize, processor layout per clip
+            pxs, grids = [], []
+            v = self.model.cfg.vision
+            for frames, dims in vids:
+                fr = eng.resize_frames(frames, dims[0], dims[1])
+                px, grid = hp.patchify(hp.normalize_frames(fr), v.patch_size, v.spatial_merge_size, v.temporal_patch_size)
+                pxs.append(px); grids.append(grid)
+            return eng.encode_video(torch.cat(pxs, 0), grids)
         if pi.get("video_frames_u8") is not None:
             # post-resize uint8 frames [N,3,H,W]: rescale + normalise + patchify run on the device (Engine.encode_frames)
             emb, plan, _ = eng.encode_frames(pi["video_frames_u8"])
@@ -79,7 +151,7 @@ class QwenGRPOTrainer:
             return eng.encode_video(pi["pixel_values_videos"], pi["video_grid_thw"])
         return None, None
 
-    def _rollout_all(self, examples, seed):
+    def _rollout_all(self, examples, seed, processed=None):
         """Rollouts of all of this rank's prompt groups.  The groups are encoded + prefilled one by one into shared-stride prefix
         slots and then decoded TOGETHER (up to MAX_DECODE_ROWS sequences per weight pass: the decode is weight-streaming bound,
         so P groups cost little more than one).  The reward functions (HTTP judge, embedding model: up to seconds per sample in
@@ -93,7 +165,7 @@ class QwenGRPOTrainer:
         pending = None
         for c0 in range(0, len(examples), per):
             chunk = examples[c0:c0 + per]
-            pis = [self.processing_fn(ex) for ex in chunk]
+            pis = processed[c0:c0 + per] if processed is not None else [self.processing_fn(ex) for ex in chunk]
             idss = [np.asarray(pi["input_ids"]).reshape(-1)[-a.max_prompt_length:] for pi in pis]
             slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="pol") if len(chunk) > 1 else [None]
             states, encs = [], []
@@ -139,33 +211,22 @@ class QwenGRPOTrainer:
 
     def _rewards(self, examples, rollouts):
         G = self.num_generations
-        prompts, completions, cols = [], [], defaultdict(list)
-        for ex, ro in zip(examples, rollouts):
-            texts = ro["decode"](ro["completion_ids"]) if ro["decode"] else [""] * G
-            for g in range(G):
-                prompts.append(ex.get("prompt"))
-                completions.append([{"role": "assistant", "content": texts[g]}])
-                for k, v in ex.items():
-                    if k not in ("prompt", "completion"):
-                        cols[k].append(v)
-        kw = dict(cols)
-        kw.update(length_reinforcement_buffer=self.args.length_reinforcement_buffer, buffer_seconds=self.args.buffer_seconds,
-                  similarity_threshold=self.args.similarity_threshold)
-        out = torch.zeros(len(prompts), len(self.reward_funcs))
-        for i, fn in enumerate(self.reward_funcs):
-            vals = fn(prompts=prompts, completions=completions, **kw)
-            out[:, i] = torch.tensor([float("nan") if v is None else float(v) for v in vals], dtype=torch.float32)
-        return out
+        texts = [ro["decode"](ro["completion_ids"]) if ro["decode"] else [""] * G for ro in rollouts]
+        for ro, t in zip(rollouts, texts):
+            ro["texts"] = t
+        return call_reward_funcs(self.reward_funcs, self.reward_func_names, examples, texts, self.args, self.sentence_model)
 
     # ------------------------------------------------------------------ one optimisation step (forward half)
-    def step(self, step_examples):
-        """step_examples: the prompt groups of THIS rank for this step (see ``iter_steps``).
+    def step(self, step_examples, processed=None):
+        """step_examples: the prompt groups of THIS rank for this step (see ``iter_steps``); processed: their processing_fn
+        results when a prefetcher already ran the host front end (train_grpo.py).
         Completions are regenerated every ``num_iterations`` steps and re-used in between, with the generation-time policy
         log-probs as the old-policy term of the ratio (grpo_trainer.py:1072-1077, :814-821)."""
         a = self.args
         mode = "train"
         if self.global_step % a.num_iterations == 0 or self._buffered is None:
-            rollouts, rewards_per_func = self._rollout_all(step_examples, seed=a.seed * 1000003 + self.global_step * 8191 + vdist.rank() * 131)
+            rollouts, rewards_per_func = self._rollout_all(step_examples, seed=a.seed * 1000003 + self.global_step * 8191 + vdist.rank() * 131,
+                                                           processed=processed)
             adv = hg.group_advantages(rewards_per_func, self.reward_weights, self.num_generations, loss_type=a.loss_type,
                                       scale_rewards=a.scale_rewards, reward_func_names=self.reward_func_names,
                                       positive_reinforcement=a.positive_reinforcement or None)
@@ -180,6 +241,16 @@ class QwenGRPOTrainer:
         eng = self.model.engine
         losses, metrics = [], defaultdict(list)
         G = self.num_generations
+        # a reference micro-batch that spans several groups (per_device_train_batch_size > G) normalises the token-mean losses
+        # by ITS token count: group g's share is tokens_g / tokens_block, applied as a scale on that group's loss and gradient
+        scale = [1.0] * len(rollouts)
+        if self.block_groups > 1 and a.loss_type in ("bnpo", "mapo_bnpo"):
+            ntok = [float(ro["completion_mask"].sum().item()) for ro in rollouts]
+            for b0 in range(0, len(rollouts), self.block_groups):
+                blk = range(b0, min(b0 + self.block_groups, len(rollouts)))
+                tot = max(sum(ntok[g] for g in blk), 1.0)
+                for g in blk:
+                    scale[g] = max(ntok[g], 1.0) / tot * len(blk)
         for i, ro in enumerate(rollouts):
             if self.update:      # policy log-probs WITH saved activations (the forward of grpo_trainer.py:1094-1096)
                 ro["logps"] = self.updater.forward(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"], a.temperature)
@@ -187,7 +258,9 @@ class QwenGRPOTrainer:
                 out = hg.grpo_loss(ro["logps"], ro["completion_mask"], adv["advantages"][i * G:(i + 1) * G].to(dev),
                                    ref_logps=ro["ref_logps"], old_logps=ro.get("old_logps"), beta=self.beta, epsilon_low=self.epsilon_low,
                                    epsilon_high=self.epsilon_high, loss_type=a.loss_type,
-                                   max_completion_length=a.max_completion_length, stream=eng.s)
+                                   max_completion_length=a.max_completion_length, norm_rows=self.norm_rows, stream=eng.s)
+                if scale[i] != 1.0:
+                    out["dlogp"].mul_(scale[i]); out["loss"] = out["loss"] * scale[i]
             if self.update:
                 self.updater.backward(out["dlogp"])                  # gradients accumulate over the step's prompt groups
             eng.sync()
@@ -215,9 +288,13 @@ class QwenGRPOTrainer:
         local["clip_ratio/low_min"] = float(np.nanmin(metrics["clip_ratio/low_mean"]))
         local["clip_ratio/high_max"] = float(np.nanmax(metrics["clip_ratio/high_mean"]))
         kinds.update({"clip_ratio/low_min": "min", "clip_ratio/high_max": "max"})
+        # per-function reward mean / std over the GLOBAL batch (nanmean / unbiased nanstd of the gathered column,
+        # grpo_trainer.py:1005-1010): reduced exactly from (count, sum, sum of squares)
         for j, name in enumerate(self.reward_func_names):
-            col = adv["rewards_per_func"][:, j]
-            local[f"rewards/{name}/mean"] = torch.nanmean(col).item()
+            col = adv["rewards_per_func"][:, j].double()
+            ok = ~torch.isnan(col)
+            local[f"_r{j}/n"] = float(ok.sum()); local[f"_r{j}/s"] = float(col[ok].sum()); local[f"_r{j}/ss"] = float((col[ok] ** 2).sum())
+            kinds.update({f"_r{j}/n": "sum", f"_r{j}/s": "sum", f"_r{j}/ss": "sum"})
         if self.update:
             lr = cosine_lr(a.learning_rate, self.global_step, self.total_steps, int(a.warmup_ratio * self.total_steps))
             gn = self.updater.optimizer_step(lr=lr, weight_decay=a.weight_decay, beta1=a.adam_beta1, beta2=a.adam_beta2,
@@ -228,21 +305,59 @@ class QwenGRPOTrainer:
                 with torch.cuda.stream(self.model.engine.stream):
                     vw.add_fp8_decode_copies(self.model.text)
         red = self.reducer.reduce(local, kinds)
+        for j, name in enumerate(self.reward_func_names):
+            n_, s_, ss_ = red.pop(f"_r{j}/n"), red.pop(f"_r{j}/s"), red.pop(f"_r{j}/ss")
+            mean = s_ / n_ if n_ > 0 else float("nan")
+            red[f"rewards/{name}/mean"] = mean
+            red[f"rewards/{name}/std"] = (max(ss_ - n_ * mean * mean, 0.0) / (n_ - 1)) ** 0.5 if n_ > 1 else float("nan")
         for k, v in red.items():
             self._metrics[mode][k].append(v)
+        if getattr(a, "log_completions", False) and self.global_step % max(1, a.logging_steps) == 0:
+            self._log_completions(step_examples, rollouts, adv)
         self.global_step += 1
         return dict(loss=red["loss"], rollouts=rollouts, advantages=adv, metrics=red, update=self.update)
 
+    def _log_completions(self, examples, rollouts, adv):
+        """prompt / completion / reward rows of this step on rank 0 (grpo_trainer.py:1016-1019, :1206-1227: console table)"""
+        G = self.num_generations
+        rows = []
+        for i, (ex, ro) in enumerate(zip(examples, rollouts)):
+            q = next((c.get("text") for m in (ex.get("prompt") or []) if isinstance(m.get("content"), list) for c in m["content"] if "text" in c), "")
+            for g, text in enumerate(ro.get("texts") or []):
+                rows.append({"step": self.global_step, "prompt": q, "completion": text, "reward": float(adv["rewards"][i * G + g])})
+        if vdist.world_size() > 1:
+            import torch.distributed as dist
+            gathered = [None] * vdist.world_size() if vdist.rank() == 0 else None
+            dist.gather_object(rows, gathered, dst=0)
+            rows = [r for part in (gathered or []) for r in part]
+        if vdist.rank() == 0:
+            self._textual_logs = rows
+            for r in rows[:4]:
+                print(f"[completions] step {r['step']} reward {r['reward']:.3f} | {r['prompt'][:80]!r} -> {r['completion'][:160]!r}")
+
     def iter_steps(self):
-        """Yields, per optimisation step, the dataset examples (one per prompt group) owned by this rank."""
+        """Yields, per optimisation step, the dataset examples (one per prompt group) owned by this rank.  One pass of the
+        seeded sampler per epoch (the order is a pure function of seed and epoch count, so a resumed run skips ahead by
+        recomputing it); each rollout batch is yielded num_iterations times (compute_loss buffer logic, :1067-1083)."""
         per_step = self.groups_per_step
-        order = list(unique_prompts(iter(self.sampler), self.num_generations))
         done = self.global_step
-        for n, s0 in enumerate(range(0, len(order) - per_step + 1, per_step)):
-            if n < done:
-                continue                                     # resume: these steps are already in the checkpoint
-            mine = vdist.shard_prompts(order[s0:s0 + per_step])
-            yield [self.train_dataset[i] for i in mine]
+        n = 0
+        epochs = float(self.args.num_train_epochs)
+        it = iter(self.sampler)                      # NB one RepeatSampler pass = one epoch; its generator keeps advancing
+        ep = 0
+        while ep < epochs:
+            order = list(unique_prompts(it, self.num_generations))
+            # the sampler repeats every chunk num_iterations times in a row: yield those repeats as consecutive steps
+            limit = len(order) if epochs - ep >= 1 else int(len(order) * (epochs - ep))
+            for s0 in range(0, limit - per_step + 1, per_step):
+                if n >= done:
+                    mine = vdist.shard_prompts(order[s0:s0 + per_step])
+                    yield [self.train_dataset[i] for i in mine]
+                n += 1
+                if self.args.max_steps > 0 and n >= self.args.max_steps:
+                    return
+            ep += 1
+            it = iter(self.sampler)
 
     # ------------------------------------------------------------------ checkpoint / resume (train_grpo.py:184-208, --save_steps)
     def save_checkpoint(self, out_dir):

@@ -1,7 +1,7 @@
 import sys, ctypes, torch
 sys.path.insert(0, '.')
 from video_r2_amd import lib
-exec(open('scratch/tune_gemv_m.py').read().split("NL = 28")[0])
+exec(open('profiles/src/tune_gemv_m.py').read().split("NL = 28")[0])
 N, K = 37888, 3584
 Ws = [torch.empty(((N + 15) // 16, K // 32 * 512), dtype=torch.bfloat16, device=dev).normal_() for _ in range(28)]
 for M in (64, 128):

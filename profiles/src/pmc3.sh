@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python scratch/pmc_train_gemms.py > gpurun_out/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python profiles/src/pmc_train_gemms.py > gpurun_out/pmc_mfma.log 2>&1
 f=$(find gpurun_out/pmc_mfma -name "*counter_collection.csv" | head -1)
 k=$(find gpurun_out/pmc_mfma -name "*kernel_trace.csv" | head -1)
 python - "$f" "$k" <<'PY'

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python scratch/pmc_gemv_w8.py ${1:-128} > gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -- python profiles/src/pmc_gemv_w8.py ${1:-128} > gpurun_out/pmc_$c.log 2>&1
   f=$(find gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
   python - "$f" $c <<'PY'
 import csv, sys

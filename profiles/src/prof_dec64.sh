@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 P=${1:-8}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dec -- python scratch/decode_only.py $P ${2:-256} > gpurun_out/dec$P.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dec -- python profiles/src/decode_only.py $P ${2:-256} > gpurun_out/dec$P.log 2>&1
 grep "ms/token" gpurun_out/dec$P.log
 f=$(find gpurun_out/prof_dec -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'

@@ -1,7 +1,7 @@
 import sys, ctypes, torch
 sys.path.insert(0, '.')
 from video_r2_amd import lib
-exec(open('scratch/tune_gemv_m.py').read().split("NL = 28")[0])
+exec(open('profiles/src/tune_gemv_m.py').read().split("NL = 28")[0])
 T = 9280
 for (M, N, name) in [(37888, 3584, "gate/up"), (3584, 18944, "down"), (4608, 3584, "qkv"), (3584, 3584, "o")]:
     A = torch.randn(T, M, device=dev).to(torch.bfloat16); B = torch.randn(T, N, device=dev).to(torch.bfloat16)

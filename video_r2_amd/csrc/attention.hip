@@ -17,7 +17,7 @@
 
 namespace {
 
-struct AttnWork {   // TOK mode work item, 8 x int32 (built on the host, see host/attn_plan.py)
+struct AttnWork {   // TOK mode work item, 8 x int32 (built on the host, see host/vision_plan.py)
   int q_row0;       // first query row in Q / out
   int nq;           // queries in this tile (<= 16 * waves)
   int ka_row0;      // source A (fully visible keys): first row in KA/VA

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
   // 64 lanes x 16 B = 1 KiB into a lane-linear KiB of LDS.  Per k-tile each wave issues 4 activation pieces (8 rows x
   // 128 B; the XOR swizzle is applied to the per-lane SOURCE address, the LDS image stays linear) and 4 weight pieces
   // (one packed 1-KiB tile each, already in fragment order).  Measured vs register staging on MI355X
-  // (scratch/gemm_bench.hip): 0.69-0.75 -> 0.87-1.06 PFLOP/s on the LM shapes.
+  // (profiles/src/gemm_bench.hip): 0.69-0.75 -> 0.87-1.06 PFLOP/s on the LM shapes.
   constexpr int NA = APIECES / 4;                      // activation pieces per wave (4 or 2)
   const bf16* ga[NA];
   const bf16* gw[4];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
 // Workgroup -> tile: ids that share an XCD (id % 8) walk groups of 8 M-tiles column by column, so the ~32 tiles an XCD has in
 // flight share 8 X panels and ~4 W panels in its L2 (group sizes 2 / 4 / 8 / 16 / all measured: 1195 / 1216 / 1235 / 1218 /
 // 1199 TFLOP/s on the LM gate/up shape).
-// Measured (scratch/gemm_bench.hip, MI355X, bf16, random operands): LM shapes at T = 9280 rows 0.97-1.23 PFLOP/s vs 0.82-0.91
+// Measured (profiles/src/gemm_bench.hip, MI355X, bf16, random operands): LM shapes at T = 9280 rows 0.97-1.23 PFLOP/s vs 0.82-0.91
 // for the 128-row tile; ViT qkv / gate-up (M = 4096) 0.95 / 0.88 vs 0.81 / 0.78.
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ Wp,
@@ -336,7 +336,7 @@ template <int EPI>
 int launch(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
            int64_t K, void* stream, void* aux = nullptr, int64_t ldaux = 0) {
   // 256-row tiles (one workgroup per CU) when their last round over the 256 CUs and their last row of tiles are mostly full
-  // (efficiency >= 0.75).  Measured crossovers (scratch/gemm_bench.hip): LM q/k/v and gate/up at T ~ 9k rows, lm_head chunks,
+  // (efficiency >= 0.75).  Measured crossovers (profiles/src/gemm_bench.hip): LM q/k/v and gate/up at T ~ 9k rows, lm_head chunks,
   // ViT q/k/v and gate/up qualify; N = 1280 and the M ~ 1k prefill projections stay on the 128-row tiles.  When the full M
   // does not qualify but its whole 256-row tiles do at >= 0.9 (N = 3584 at T = 9280: 37 x 14 tiles = 2.02 rounds, 36 x 14 =
   // 1.97), the first M - M % 256 rows take the 256-row kernel and the few tail rows the 128-row one.

@@ -8,7 +8,7 @@
 // lane l = 16*(k%32/8) + n%16 owns the 16 bytes W[n][8*(k/8) .. +7] -- exactly the v_mfma_f32_16x16x32_bf16 A
 // fragment.  One wave-level global_load_dwordx4 therefore fetches ONE CONTIGUOUS KiB that is already the MFMA operand:
 // no LDS round trip, no cross-lane reduction, almost no VALU.  Measured on MI355X at the 7B gate/up shape
-// (scratch/gemv_bench.hip): row-major fragment-shaped loads (16 rows x 64 B per instruction) 4.0 TB/s, packed tiles
+// (profiles/src/gemv_bench.hip): row-major fragment-shaped loads (16 rows x 64 B per instruction) 4.0 TB/s, packed tiles
 // 5.6 TB/s, packed + two weight tiles per activation fragment 6.3 TB/s (plain streaming read: 6.9 TB/s).
 // A wave streams TWO weight tiles per k-step against one activation (B) fragment; the 4 waves of a workgroup split K
 // and reduce through LDS; an optional grid-level split-K writes separate fp32 partial slabs which the NEXT kernel

@@ -437,7 +437,7 @@ class Engine:
         schunk = self._suffix_chunk(G)
         npc, nsc = (n_prompt + pchunk - 1) // pchunk, (C + schunk - 1) // schunk
         nchunk = npc + nsc
-        # grid-level split-K per projection (scratch/tune_gemv.py on MI355X): enough workgroups to cover 256 CUs
+        # grid-level split-K per projection (profiles/src/tune_gemv.py on MI355X): enough workgroups to cover 256 CUs
         def pick(k, want):
             while want > 1 and (k // 32) < want * 4:
                 want //= 2

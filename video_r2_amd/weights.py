@@ -7,7 +7,7 @@ it into the engine's own HBM layout (the engine owns these buffers; the caller k
 * matrices bf16, TILE-PACKED: K padded to a multiple of 64 and N to 16 (zero fill), then stored as 16-row x 32-k tiles
   of 1 KiB in v_mfma_f32_16x16x32_bf16 A-fragment order (``pack_tiles``; layout contract in include/vr2.h).  One
   wave-level 16-byte load = one contiguous KiB that is already an MFMA operand: decode streams weights at 6.3 TB/s
-  instead of 4.0 TB/s for row-major (scratch/gemv_bench.hip), and the prefill GEMM stages them with straight copies.
+  instead of 4.0 TB/s for row-major (profiles/src/gemv_bench.hip), and the prefill GEMM stages them with straight copies.
 * q/k/v fused into one [nq*hd + 2*nkv*hd][H] matrix; gate/up fused into [2*I16][H] with the two matrices INTERLEAVED by
   16-row tiles (gate tile p, up tile p, gate tile p+1, ...; I16 = I rounded up to 16) so that one MFMA lane holds the
   gate and the up value of the same output column and silu(g)*u is a register epilogue (``interleave_gate_up``)

@@ -287,7 +287,8 @@ def main():
                 adv = hg.group_advantages(torch.from_numpy(stub_rewards(comp)).to(device), [1.0], G, loss_type="bnpo")["advantages"]
                 out = hg.grpo_loss(lp, mask, adv, ref_logps=lp_ref, beta=0.04, loss_type="bnpo", stream=eng.s)
             if upd is not None:
-                upd.backward(out["dlogp"])                           # gradients accumulate over the step's prompt groups
+                upd.backward(out["dlogp"], exchange=(p_ == Pn - 1))    # gradients accumulate over the groups; the last backward
+                                                                       # puts each layer's bucket on the wire as it completes
             mark("loss+backward")
             loss += float(out["loss"].item()) / Pn
         mark(None)

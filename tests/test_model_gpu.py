@@ -159,15 +159,20 @@ def test_trainer_step_metrics_and_loss():
         assert k in out["metrics"], k
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, backend="gloo"):
     import os
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                      VR2_DIST_BACKEND="gloo")
+    local = rank if backend == "nccl" else 0                     # RCCL wants one GPU per rank; the gloo rehearsal shares GPU 0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
+                      VR2_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from video_r2_amd import dist as vdist, params, rewards
+    from video_r2_amd.model import VideoR2Model
     from video_r2_amd.trainer import QwenGRPOTrainer
-    vdist.init()
-    m, w, ocfg = _model(2, 29)
+    torch.cuda.set_device(local)
+    vdist.init(device=f"cuda:{local}")
+    ocfg = om.cfg_tiny(2)
+    w = om.make_weights(ocfg, seed=29)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), w, device=f"cuda:{local}")
     cfg = m.cfg
     args = params.parse_args(["--num_generations", "4", "--max_completion_length", "8", "--beta", "0.04", "--loss_type", "bnpo",
                               "--reward_func_names", "format_reward", "--reward_weights", "1.0", "--learning_rate", "1e-3"])
@@ -177,7 +182,7 @@ def _dp_worker(rank, world, port, q):
         px, grid = pixels_from_frames(frames, cfg.vision)
         tv = grid[0] * grid[1] * grid[2] // 4
         ids = [40 + ex["vid"], cfg.vision_start_token_id] + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 50, 51]
-        return dict(input_ids=np.asarray(ids), pixel_values_videos=torch.from_numpy(px).cuda(), video_grid_thw=[grid], second_per_grid_ts=[1.0],
+        return dict(input_ids=np.asarray(ids), pixel_values_videos=torch.from_numpy(px).to(m.device), video_grid_thw=[grid], second_per_grid_ts=[1.0],
                     decode=lambda toks: ["<think>t</think> <answer>B</answer>" if (i + ex["vid"]) % 2 else "nope" for i in range(toks.shape[0])])
 
     data = [dict(prompt=[{"role": "user", "content": "q"}], vid=i) for i in range(8)]
@@ -186,6 +191,7 @@ def _dp_worker(rank, world, port, q):
     steps = list(tr.iter_steps())
     out = tr.step(steps[0])
     torch.cuda.synchronize()
+    assert tr.updater._works == {}                               # every bucket was exchanged and waited for
     q.put((rank, [ex["vid"] for ex in steps[0]], out["metrics"]["loss"], out["metrics"]["grad_norm"],
            m.text["l0.o_w"].float().sum().item(), m.text["l1.ln2"].sum().item()))
     dist.barrier()
@@ -211,6 +217,26 @@ def test_two_rank_dp_step_keeps_replicas_identical():
     assert v0 != v1 and len(v0) == len(v1) == 1                  # different prompt groups per rank
     assert l0 == l1 and g0 == g1 and g0 > 0                      # reduced metrics agree; the clipped norm is of the MEAN gradient
     assert w0 == w1 and n0 == n1                                 # replicas stay bit-identical after the update
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two GPUs (the gloo rehearsal above runs the same code on one)")
+def test_two_rank_dp_step_on_rccl():
+    """the same step on the "nccl" backend (RCCL over xGMI), one GPU per rank: per-layer gradient buckets all-reduced on RCCL's
+    stream under the backward, packed metrics all-reduce on the device, replicas bit-identical afterwards"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, v0, l0, g0, w0, n0), (r1, v1, l1, g1, w1, n1) = res
+    assert v0 != v1 and l0 == l1 and g0 == g1 and g0 > 0 and w0 == w1 and n0 == n1
 
 
 def test_checkpoint_resume_and_num_iterations(tmp_path):

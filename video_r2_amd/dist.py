@@ -4,9 +4,11 @@ Replaces the reference's accelerate + DeepSpeed ZeRO-3 stack f
 (7B bf16 + reference + fp32 optimizer state fit in 288 GB), prompt GROUPS are sharded over ranks so rewards and group
 advantages need no collective (C1, C4-C7 eliminated), and the only exchanges per step are
   * one packed fp32 metrics all-reduce (C2/C8), and
-  * one bucketed all-reduce (mean) of the trainable-gradient flat buffer (C5 replacement), overlappable with backward.
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 512 MiB) so each collective runs
-bandwidth-bound on all peers rather than latency-bound.
+  * one bucketed all-reduce (mean) of the trainable-gradient arena (C5 replacement): train.py lays the gradients out in
+    backward-completion order and issues one bucket (a layer, ~0.93 GB fp32 at 7B) per backward stage, under the rest of the
+    backward.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the buckets are large so each collective runs bandwidth-bound on all
+peers rather than latency-bound.
 """
 from __future__ import annotations
 

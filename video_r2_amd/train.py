@@ -28,7 +28,13 @@ from .weights import Params, pack_tiles, pad64, unpack_tiles
 
 
 class TrainState:
-    """fp32 masters, gradients and Adam moments of the trainable LM tensors + the transposed packed copies for dgrad."""
+    """fp32 masters, gradients and Adam moments of the trainable LM tensors + the transposed packed copies for dgrad.
+
+    The gradients live in ONE contiguous fp32 arena, laid out in the order the backward pass finishes them (lm_head + final
+    norm, then layer L-1 ... layer 0, then the embedding rows): a bucket = one contiguous slice = everything one backward
+    stage produced, so the data-parallel exchange is one all-reduce per bucket, issued the moment the stage's last weight
+    gradient is enqueued and running on RCCL's stream under the rest of the backward (the single
+    gradient exchange that replaces ZeRO-3's gathers / reduce-scatters)."""
 
     def __init__(self, text: Params, device):
         self.text = text
@@ -39,7 +45,8 @@ class TrainState:
         self.t_name = {}
         cfg = text.cfg
         t = cfg.text
-        mats = [f"l{i}.{n}" for i in range(t.num_hidden_layers) for n in ("qkv_w", "o_w", "gu_w", "down_w")] + ["lm_head"]
+        L = t.num_hidden_layers
+        mats = [f"l{i}.{n}" for i in range(L) for n in ("qkv_w", "o_w", "gu_w", "down_w")] + ["lm_head"]
         for name in mats:
             n, kp = text.shape[name]
             w = unpack_tiles(text[name], n, kp)                      # [N][Kp] bf16 (K padding columns are zero)
@@ -50,9 +57,25 @@ class TrainState:
             text.shape[name + "_t"] = (kp, pad64(n))
         self.tied = t.tie_word_embeddings
         self._add("embed", text["embed"].float(), "rows", True)
-        vecs = [f"l{i}.{n}" for i in range(t.num_hidden_layers) for n in ("ln1", "ln2", "qkv_b")] + ["norm"]
+        vecs = [f"l{i}.{n}" for i in range(L) for n in ("ln1", "ln2", "qkv_b")] + ["norm"]
         for name in vecs:
             self._add(name, text[name], "vec", False)                # the fp32 vector IS its own master (updated in place)
+        # ---- gradient arena in backward-completion order; buckets = (key, first element, one-past-last element)
+        order = [("head", ["lm_head", "norm"])]
+        order += [(l, [f"l{l}.{n}" for n in ("down_w", "gu_w", "ln2", "o_w", "qkv_b", "qkv_w", "ln1")]) for l in reversed(range(L))]
+        order += [("embed", ["embed"])]
+        total = sum(self.master[n].numel() for _, names in order for n in names)
+        assert total == sum(m.numel() for m in self.master.values())
+        self.arena = torch.zeros(total, dtype=torch.float32, device=device)
+        self.buckets = []
+        at = 0
+        for key, names in order:
+            first = at
+            for n in names:
+                k = self.master[n].numel()
+                self.grad[n] = self.arena[at:at + k].view(self.master[n].shape)
+                at += k
+            self.buckets.append((key, first, at))
         self.step_count = 0
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
         self.coef = torch.ones(1, dtype=torch.float32, device=device)
@@ -60,15 +83,13 @@ class TrainState:
 
     def _add(self, name, master, kind, decay):
         self.master[name] = master.contiguous()
-        self.grad[name] = torch.zeros_like(self.master[name])
         self.m[name] = torch.zeros_like(self.master[name])
         self.v[name] = torch.zeros_like(self.master[name])
         self.kind[name] = kind
         self.decay[name] = decay     # HF Trainer: no weight decay on biases and norm weights
 
     def zero_grad(self):
-        for g in self.grad.values():
-            g.zero_()
+        self.arena.zero_()
 
     def n_params(self):
         return sum(m.numel() for m in self.master.values())
@@ -82,6 +103,7 @@ class Trainer:
         self.text = text
         self.state = TrainState(text, engine.device)
         self._saved = None
+        self._works = {}          # bucket key -> in-flight all-reduce of this optimiser step
 
     @property
     def device(self):
@@ -101,6 +123,17 @@ class Trainer:
 
     def _cast(self, src, dst, T, H):
         lib.call("vr2_cast_rows_f32_bf16", src, src.stride(0), None, dst, dst.stride(0), T, H, H, self.eng.s)
+
+    # ------------------------------------------------------------------ data-parallel gradient exchange
+    def _exchange(self, key):
+        """SUM all-reduce of one arena bucket, asynchronous: torch's process group (RCCL on the "nccl" backend) orders it
+        after everything already enqueued on the engine stream and runs it on its own stream, under the kernels enqueued
+        next.  The 1/world of the mean is folded into the clip coefficient (optimizer_step)."""
+        if vdist.world_size() == 1 or key in self._works:
+            return
+        import torch.distributed as dist
+        _, first, last = next(b for b in self.state.buckets if b[0] == key)
+        self._works[key] = dist.all_reduce(self.state.arena[first:last], op=dist.ReduceOp.SUM, async_op=True)
 
     # ------------------------------------------------------------------ forward with saved activations
     @_on_stream
@@ -185,8 +218,11 @@ class Trainer:
 
     # ------------------------------------------------------------------ backward (accumulates into TrainState.grad)
     @_on_stream
-    def backward(self, dlogp):
+    def backward(self, dlogp, exchange=False):
+        """exchange=True on the LAST backward of an optimiser step (gradients accumulate over the step's prompt groups): every
+        stage's bucket is all-reduced as soon as its weight gradients are enqueued, overlapping the rest of this backward."""
         eng, W, cfg, st = self.eng, self.text, self.eng.cfg, self.state
+        exchange = exchange and vdist.world_size() > 1 and not st.tied     # tied lm_head / embedding: summed first, at the step
         s = self._saved
         assert s is not None, "backward() needs a preceding forward()"
         t = cfg.text
@@ -213,6 +249,8 @@ class Trainer:
         dhs = b("t.dhs", (R, H), torch.float32)
         rinv = b("t.rinv", (max(T, R),), torch.float32)
         lib.call("vr2_rmsnorm_bwd", s["hs"], H, W["norm"], dhn, H, dhs, H, rinv, st.grad["norm"], R, H, t.rms_norm_eps, 0, eng.s)
+        if exchange:
+            self._exchange("head")
         dx = b("t.dx", (T, H), torch.float32)
         dx.zero_()
         dv_, dc = dhs.view(G, C, H), dx[S:].view(G, C, H)
@@ -259,10 +297,14 @@ class Trainer:
             self._wgrad(dqkv, sv["xn1"][l], f"l{l}.qkv_w", nqkv, H, T)
             lib.call("vr2_rmsnorm_bwd", sv["x_in"][l], H, W[f"l{l}.ln1"], dxn, H, dx, H, rinv, st.grad[f"l{l}.ln1"], T, H,
                      t.rms_norm_eps, 1, eng.s)
+            if exchange:
+                self._exchange(l)
         # ---- embedding rows (video placeholder rows carry frozen vision features: no gradient)
         skip = _i32([cfg.video_token_id if s["has_video"] else -1], eng.device)
         ge = st.grad["embed"]
         lib.call("vr2_embed_bwd", s["ids"], skip, dx, dx.stride(0), ge, ge.stride(0), T, H, eng.s)
+        if exchange:
+            self._exchange("embed")
         self._saved = None
 
     # ------------------------------------------------------------------ checkpoint resume
@@ -292,9 +334,14 @@ class Trainer:
         eng, st, W = self.eng, self.state, self.text
         if st.tied:
             st.grad["embed"].add_(st.grad["lm_head"])        # one shared parameter (Qwen2.5-VL-3B)
-        if vdist.world_size() > 1:
-            for g in st.grad.values():                        # one flat bucket per tensor: the big ones are 0.1-2.2 GB each
-                vdist.allreduce_mean_(g.view(-1))
+        world = vdist.world_size()
+        if world > 1:
+            for key, _, _ in st.buckets:                      # whatever the last backward did not already put on the wire
+                self._exchange(key)
+            for wk in self._works.values():
+                wk.wait()                                     # the engine stream waits for RCCL's; the host does not
+            self._works = {}
+            grad_scale = grad_scale / world                   # SUM -> mean, folded into the clip coefficient
         names = [n_ for n_ in st.grad if not (st.tied and n_ == "lm_head")]
         slot_f = int(lib.load().vr2_sumsq_slot_floats())
         if st.sumsq.numel() != len(names) * slot_f:

@@ -262,7 +262,7 @@ class QwenGRPOTrainer:
                 if scale[i] != 1.0:
                     out["dlogp"].mul_(scale[i]); out["loss"] = out["loss"] * scale[i]
             if self.update:
-                self.updater.backward(out["dlogp"])                  # gradients accumulate over the step's prompt groups
+                self.updater.backward(out["dlogp"], exchange=(i == len(rollouts) - 1))   # gradients accumulate over the groups
             eng.sync()
             ro["dlogp"] = out["dlogp"]
             losses.append(out["loss"].item() / len(rollouts))       # Trainer divides by the accumulation count

@@ -250,6 +250,7 @@ def main():
     n_prompts = (a.steps + a.warmup + 1) * P + 2            # + one instrumented step for the phase split + 2 recipe-shaped steps
     prompts = [synth_prompt(cfg, a.frames, rank * 1000 + i, device) for i in range(n_prompts)]
     slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="pol")
+    ref_slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="ref")
     torch.cuda.synchronize()
 
     def step(i, rec=None, mine=None):
@@ -257,25 +258,25 @@ def main():
         mark = rec if rec is not None else (lambda name: None)
         mine = prompts[i * P:(i + 1) * P] if mine is None else mine
         Pn = len(mine)
-        enc, states = [], []
-        for p_, (px, grid, ids) in enumerate(mine):
-            mark(None)
-            emb, plan = eng.encode_video(px, [grid])
-            emb = emb.clone() if Pn > 1 else emb                     # the ViT output workspace is reused by the next group
-            mark("vit")
-            enc.append((emb, plan))
-            states.append(eng.prefill(pol, ids, emb, plan, [1.0], tag="pol", prefix_out=slots[p_]))
-            mark("prefill")
+        # the step's P clips go through the vision tower in ONE pass and its P prompts through ONE policy prefill and ONE
+        # reference prefill (M = P x 4096 patches / P x S tokens: every projection runs on full 256-row tiles)
+        mark(None)
+        enc = eng.encode_videos([dict(pixel_values=px, grid=grid) for px, grid, _ in mine])
+        mark("vit")
+        states = eng.prefill_batch(pol, [(ids, enc[p_][0], enc[p_][1], [1.0]) for p_, (_, _, ids) in enumerate(mine)], slots[:Pn], tag="pol")
+        mark("prefill")
         toks_all, _ = eng.decode(pol, states, G, C, temperature=0.9, top_k=50, seed=1000 * rank + i, eos_token_id=None,
                                  use_graph=not a.no_graph)
         mark("decode")
         loss = 0.0
+        mark(None)
+        ref_states = eng.prefill_batch(ref, [(ids, enc[p_][0], enc[p_][1], [1.0]) for p_, (_, _, ids) in enumerate(mine)], ref_slots[:Pn], tag="ref")
+        mark("ref_prefill+ref_score")
         for p_, (px, grid, ids) in enumerate(mine):
             emb, plan = enc[p_]
             toks = toks_all[p_ * G:(p_ + 1) * G]
             mark(None)
-            st_ref = eng.prefill(ref, ids, emb, plan, [1.0], tag="ref")
-            lp_ref = eng.score(ref, st_ref, toks, 0.9, tag="ref")
+            lp_ref = eng.score(ref, ref_states[p_], toks, 0.9, tag="ref")
             mark("ref_prefill+ref_score")
             lp = eng.score(pol, states[p_], toks, 0.9, tag="pol") if upd is None else upd.forward(ids, emb, plan, [1.0], toks, 0.9)
             mark("policy_forward")

@@ -98,6 +98,11 @@ int vr2_mrope_table(const void* pos3_i32, int64_t T, const void* inv_freq_f32, c
 int vr2_rope_qkv(const void* qkv_f32, int64_t ld, const void* cos_f32, const void* sin_f32, int64_t T, int64_t nq,
                  int64_t nkv, int64_t head_dim, void* q_out_bf16, int64_t ldq, void* k_out_bf16, void* v_out_bf16,
                  int64_t ldkv, int64_t kv_row0, void* stream);
+/* the same for a BATCH of prompts prefilled in one row space (row t = prompt t / seg_rows, token t % seg_rows): k / v rows go
+ * to per-prompt cache slots seg_stride rows apart, row (t / seg_rows) * seg_stride + t % seg_rows */
+int vr2_rope_qkv_seg(const void* qkv_f32, int64_t ld, const void* cos_f32, const void* sin_f32, int64_t T, int64_t nq,
+                     int64_t nkv, int64_t head_dim, void* q_out_bf16, int64_t ldq, void* k_out_bf16, void* v_out_bf16,
+                     int64_t ldkv, int64_t seg_rows, int64_t seg_stride, void* stream);
 /* decode: qkv = bias + sum partial; rope at position pos[g] + step[0]; q -> q_out, k/v -> cache row g*rows_per_seq+step */
 int vr2_rope_append_decode(const void* partial_f32, int64_t split_stride, int64_t ldp, int nsplit, const void* bias_f32,
                            const void* pos_i32, const void* step_i32, const void* inv_freq_f32, int64_t G, int64_t nq,

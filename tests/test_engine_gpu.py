@@ -414,3 +414,91 @@ def test_text_only_prompt_logps_vs_oracle():
     lp_last = torch.log_softmax(b["logits"][:G].float() / 0.9, -1).gather(1, torch.from_numpy(comp[:, -1:]).to(eng.device).long()).squeeze(1)
     r2 = rel_err(lp_last.cpu().numpy(), want[:, -1])
     assert r2.max() < 2e-3, r2.max()
+
+
+def test_batched_vision_and_prefill_equal_the_one_by_one_path(golden_dir):
+    """encode_videos / prefill_batch (one row space for the clips / prompts of a step) against encode_video / prefill one at a
+    time: ragged prompt lengths, different clip geometries, a prompt with two clips, a text-only prompt, uint8 clips with
+    device resize; the golden HF log-probs through the batched path; K/V slots, logits and scores identical to the single path
+    (same MFMA k-order in every tile shape, so the equality is exact)."""
+    from video_r2_amd.host.processor import video_prompt_ids
+    f = _load(golden_dir, "fwd_tiny_g2")
+    ocfg = om.cfg_tiny(2)
+    eng, w, cfg = make_engine(ocfg, int(f["seed"]))
+    g = torch.Generator().manual_seed(3)
+    dev = eng.device
+    clips, prompts = [], []
+    geos = [((2, 56, 84), 5), ((4, 84, 56), 11), ((2, 56, 56), 2)]
+    for (n, hh, ww), ntxt in geos:
+        frames = torch.randint(0, 256, (n, 3, hh, ww), generator=g, dtype=torch.uint8)
+        px, grid = pixels_from_frames(frames.numpy(), cfg.vision)
+        clips.append((frames, torch.from_numpy(px).to(dev), grid))
+        tv = grid[0] * grid[1] * grid[2] // 4
+        prompts.append(np.asarray(video_prompt_ids(cfg, tv, [11, 12], list(range(30, 30 + ntxt)))))
+    # prompt 3: two clips (clips 0 and 2) in one prompt; prompt 4: text only
+    tv0 = clips[0][2][0] * clips[0][2][1] * clips[0][2][2] // 4
+    tv2 = clips[2][2][0] * clips[2][2][1] * clips[2][2][2] // 4
+    two = [9, cfg.vision_start_token_id] + [cfg.video_token_id] * tv0 + [cfg.vision_end_token_id, 40, cfg.vision_start_token_id] + \
+          [cfg.video_token_id] * tv2 + [cfg.vision_end_token_id, 41, 42]
+    prompts.append(np.asarray(two))
+    prompts.append(np.asarray([5, 6, 7, 8, 9, 10, 11]))
+    # --- one by one
+    single = []
+    for k in range(3):
+        emb, plan = eng.encode_video(clips[k][1], [clips[k][2]])
+        single.append((emb.clone(), plan))
+    emb2, plan2 = eng.encode_video(torch.cat([clips[0][1], clips[2][1]]), [clips[0][2], clips[2][2]])
+    single.append((emb2.clone(), plan2))
+    single.append((None, None))
+    secs = [[1.0], [2.0], [1.0], [1.0, 1.0], None]
+    comp = torch.randint(20, 500, (len(prompts), 3, 6), generator=g)
+    ref_states, ref_scores = [], []
+    for k, ids in enumerate(prompts):
+        st = eng.prefill(eng.text, ids, single[k][0], single[k][1], secs[k], tag="one")
+        ref_states.append((st.prefix_k[:, :len(ids)].clone(), st.prefix_v[:, :len(ids)].clone(), st.last_logits.clone(), st.rope_delta))
+        ref_scores.append(eng.score(eng.text, st, comp[k], 0.9, tag="one").clone())
+    # --- batched: clips as uint8 frames (prompt 1 through the device resize to its own size = identity), one prefill
+    flat = [dict(frames_u8=clips[0][0], resize_to=None), dict(pixel_values=clips[1][1], grid=clips[1][2]), dict(frames_u8=clips[2][0], resize_to=(56, 56)),
+            dict(pixel_values=clips[0][1], grid=clips[0][2]), dict(frames_u8=clips[2][0], resize_to=None)]
+    enc = eng.encode_videos(flat, per_prompt=[1, 1, 1, 2, 0])
+    assert enc[4] == (None, None) and enc[3][1].n_tokens == tv0 + tv2
+    for k in range(4):
+        assert torch.equal(enc[k][0], single[k][0]), k            # same patch rows, same window order, same kernels
+    slots = eng.prefix_slots(len(prompts), max(len(p) for p in prompts), tag="bat")
+    states = eng.prefill_batch(eng.text, [(prompts[k], enc[k][0], enc[k][1], secs[k]) for k in range(len(prompts))], slots, tag="bat")
+    eng.sync()
+    for k, (st, ids) in enumerate(zip(states, prompts)):
+        rk, rv, rl, rd = ref_states[k]
+        assert st.n_prompt == len(ids) and st.rope_delta == rd
+        assert torch.equal(st.prefix_k[:, :len(ids)], rk) and torch.equal(st.prefix_v[:, :len(ids)], rv), k
+        assert torch.equal(st.last_logits, rl), k
+        assert torch.equal(eng.score(eng.text, st, comp[k], 0.9, tag="bat"), ref_scores[k]), k
+    # pieces: a row budget that holds only two of the prompts per pass gives the same states
+    slots2 = eng.prefix_slots(len(prompts), max(len(p) for p in prompts), tag="bat2")
+    states2 = eng.prefill_batch(eng.text, [(prompts[k], enc[k][0], enc[k][1], secs[k]) for k in range(len(prompts))], slots2, tag="bat2",
+                                max_rows=2 * max(len(p) for p in prompts))
+    eng.sync()
+    for a_, b_, ids in zip(states, states2, prompts):
+        assert torch.equal(a_.last_logits, b_.last_logits) and torch.equal(a_.prefix_k[:, :len(ids)], b_.prefix_k[:, :len(ids)])
+    # all five groups decoded together from the batched slots == each group decoded alone from its one-by-one prefill
+    forced = comp.reshape(-1, 6).numpy()
+    _, b = eng.decode(eng.text, states, 3, 6, temperature=0.9, top_k=50, seed=1, forced_tokens=forced, use_graph=False)
+    eng.sync()
+    together = b["logits"].clone()
+    for k, ids in enumerate(prompts):
+        st = eng.prefill(eng.text, ids, single[k][0], single[k][1], secs[k], tag="one")
+        _, b1 = eng.decode(eng.text, st, 3, 6, temperature=0.9, top_k=50, seed=1, forced_tokens=comp[k].numpy(), use_graph=False)
+        eng.sync()
+        r = rel_err(torch.log_softmax(together[3 * k:3 * k + 3], -1).cpu().numpy(), torch.log_softmax(b1["logits"][:3], -1).cpu().numpy())
+        assert r.max() < 1e-3, (k, r.max())
+    # the golden HF log-probs through the batched path
+    ids, am = f["input_ids"][0], f["attention_mask"][0].astype(bool)
+    C = int(f["C"])
+    seq = ids[am]
+    prompt, cmp_ = seq[:-C], seq[-C:]
+    px, grid = pixels_from_frames(f["frames_u8"], cfg.vision)
+    (emb, plan), = eng.encode_videos([dict(pixel_values=torch.from_numpy(px).to(dev), grid=grid)])
+    st, = eng.prefill_batch(eng.text, [(prompt, emb, plan, [float(f["sec"])])], eng.prefix_slots(1, len(prompt), tag="g"), tag="g")
+    lp = eng.score(eng.text, st, cmp_[None, :], float(f["temperature"]))
+    eng.sync()
+    assert rel_err(lp.cpu().numpy(), f["hf_logps"]).max() < LOGP_TOL

@@ -223,8 +223,12 @@ __global__ void mrope_table_kernel(const int* __restrict__ pos, long T, const fl
 __global__ __launch_bounds__(256) void rope_qkv_kernel(const float* __restrict__ qkv, long ld, const float* __restrict__ cs,
                                                        const float* __restrict__ sn, int nq, int nkv, int hd,
                                                        bf16* __restrict__ q_out, long ldq, bf16* __restrict__ kdst,
-                                                       bf16* __restrict__ vdst, long ldkv, long kv_row0) {
+                                                       bf16* __restrict__ vdst, long ldkv, long kv_row0, int seg_rows,
+                                                       long seg_stride) {
   const int t = blockIdx.x;
+  // K/V destination row: t, or -- batched prefill of several prompts into per-prompt cache slots -- row t % seg_rows of
+  // the slot t / seg_rows, slots seg_stride rows apart
+  const long drow = kv_row0 + (seg_rows > 0 ? (long)(t / seg_rows) * seg_stride + (t % seg_rows) : (long)t);
   const int half = hd / 2;
   const float* row = qkv + (long)t * ld;
   const float* c = cs + (long)t * half;
@@ -236,12 +240,12 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(const float* __restrict__
     const float x1 = p[j], x2 = p[j + half];
     const float o1 = x1 * c[j] - x2 * s[j];
     const float o2 = x2 * c[j] + x1 * s[j];
-    bf16* d = (h < nq) ? (q_out + (long)t * ldq + h * hd) : (kdst + (kv_row0 + t) * ldkv + (h - nq) * hd);
+    bf16* d = (h < nq) ? (q_out + (long)t * ldq + h * hd) : (kdst + drow * ldkv + (h - nq) * hd);
     d[j] = f2bf(o1);
     d[j + half] = f2bf(o2);
   }
   const float* v = row + (long)(nq + nkv) * hd;
-  bf16* vd = vdst + (kv_row0 + t) * ldkv;
+  bf16* vd = vdst + drow * ldkv;
   for (int i = threadIdx.x * 4; i < nkv * hd; i += 1024) {
     const float4 x = *reinterpret_cast<const float4*>(v + i);
     bf16x4 o = {f2bf(x.x), f2bf(x.y), f2bf(x.z), f2bf(x.w)};
@@ -418,8 +422,20 @@ extern "C" int vr2_rope_qkv(const void* qkv_f32, int64_t ld, const void* cos_f32
   VR2_REQUIRE(q_out_bf16 && k_out_bf16 && v_out_bf16 && ldkv % 4 == 0, "vr2_rope_qkv: outputs missing");
   hipLaunchKernelGGL(rope_qkv_kernel, dim3((unsigned)T), dim3(256), 0, STREAM, (const float*)qkv_f32, (long)ld,
                      (const float*)cos_f32, (const float*)sin_f32, (int)nq, (int)nkv, (int)head_dim, (bf16*)q_out_bf16,
-                     (long)ldq, (bf16*)k_out_bf16, (bf16*)v_out_bf16, (long)ldkv, (long)kv_row0);
+                     (long)ldq, (bf16*)k_out_bf16, (bf16*)v_out_bf16, (long)ldkv, (long)kv_row0, 0, 0L);
   return vr2_check_launch("vr2_rope_qkv");
+}
+
+extern "C" int vr2_rope_qkv_seg(const void* qkv_f32, int64_t ld, const void* cos_f32, const void* sin_f32, int64_t T, int64_t nq,
+                                int64_t nkv, int64_t head_dim, void* q_out_bf16, int64_t ldq, void* k_out_bf16,
+                                void* v_out_bf16, int64_t ldkv, int64_t seg_rows, int64_t seg_stride, void* stream) {
+  VR2_REQUIRE(T >= 1 && head_dim % 8 == 0 && ld >= (nq + 2 * nkv) * head_dim && ld % 4 == 0, "vr2_rope_qkv_seg: bad shape");
+  VR2_REQUIRE(q_out_bf16 && k_out_bf16 && v_out_bf16 && ldkv % 4 == 0, "vr2_rope_qkv_seg: outputs missing");
+  VR2_REQUIRE(seg_rows >= 1 && seg_stride >= seg_rows, "vr2_rope_qkv_seg: seg_rows=%ld seg_stride=%ld", (long)seg_rows, (long)seg_stride);
+  hipLaunchKernelGGL(rope_qkv_kernel, dim3((unsigned)T), dim3(256), 0, STREAM, (const float*)qkv_f32, (long)ld,
+                     (const float*)cos_f32, (const float*)sin_f32, (int)nq, (int)nkv, (int)head_dim, (bf16*)q_out_bf16,
+                     (long)ldq, (bf16*)k_out_bf16, (bf16*)v_out_bf16, (long)ldkv, 0L, (int)seg_rows, (long)seg_stride);
+  return vr2_check_launch("vr2_rope_qkv_seg");
 }
 
 extern "C" int vr2_rope_append_decode(const void* partial_f32, int64_t split_stride, int64_t ldp, int nsplit,

@@ -238,6 +238,71 @@ class Engine:
         lib.call("vr2_cast_rows_f32_bf16", px, px.stride(0), pl.d_gather, a0, a0.stride(0), P, v.patch_dim, Kp, self.s)
         return self._vision_blocks(pl, a0), pl
 
+    @_on_stream
+    def encode_videos(self, clips, per_prompt=None):
+        """Several clips through ONE pass of the vision tower (M = all their patches: the N = 1280 / 3420 projections then run
+        on full 256-row tiles instead of one 4096-patch clip at a time).  clips: list of dict(pixel_values=f32 [P_i, C*tp*ps*ps],
+        grid=(t,h,w)) or dict(frames_u8=uint8 [n,3,H,W], resize_to=(H', W') | None).  per_prompt: how many consecutive clips
+        each prompt owns (default: one each; 0 = a prompt without video -> (None, None)).  -> per prompt (video tokens f32
+        [Tv, out_hidden] in the window order of the plan over ITS clips, that plan); views of one buffer owned by the caller."""
+        import ctypes
+        from .host import processor as hp
+        v = self.cfg.vision
+        Kp = pad64(v.patch_dim)
+        metas = []
+        for c in clips:
+            if c.get("frames_u8") is not None:
+                fr = torch.as_tensor(c["frames_u8"])
+                if fr.dtype != torch.uint8 or fr.dim() != 4 or fr.shape[1] != 3:
+                    raise ValueError(f"encode_videos wants uint8 [N,3,H,W] frames, got {fr.dtype} {tuple(fr.shape)}")
+                if c.get("resize_to") is not None:
+                    fr = self.resize_frames(fr, c["resize_to"][0], c["resize_to"][1])
+                n, _, hh, ww = (int(a) for a in fr.shape)
+                unit = v.patch_size * v.spatial_merge_size
+                if hh % unit or ww % unit:
+                    raise ValueError(f"frame size {hh}x{ww} is not a multiple of {unit} (smart_resize first)")
+                grid = ((n + v.temporal_patch_size - 1) // v.temporal_patch_size, hh // v.patch_size, ww // v.patch_size)
+                metas.append(("u8", fr.to(self.device).contiguous(), grid))
+            else:
+                grid = tuple(int(x) for x in np.asarray(c["grid"]).reshape(-1))
+                px = c["pixel_values"]
+                if px.shape[0] != grid[0] * grid[1] * grid[2] or px.shape[1] != v.patch_dim:
+                    raise ValueError(f"pixel_values shape {tuple(px.shape)} does not match grid {grid}")
+                metas.append(("px", px.to(device=self.device, dtype=torch.float32).contiguous(), grid))
+        grids = [m[2] for m in metas]
+        per_prompt = [1] * len(metas) if per_prompt is None else list(per_prompt)
+        if sum(per_prompt) != len(metas):
+            raise ValueError(f"per_prompt {per_prompt} does not add up to {len(metas)} clips")
+        if not metas:
+            return [(None, None)] * len(per_prompt)
+        pl_all = self.vision_plan(grids)
+        a0 = self.buf("v.px", (pl_all.n_patches, Kp), torch.bfloat16)
+        singles, row = [], 0
+        for kind, data, grid in metas:
+            pl = self.vision_plan([grid])
+            dst = a0[row:row + pl.n_patches]
+            if kind == "u8":
+                n, _, hh, ww = (int(a) for a in data.shape)
+                mean = (torch.tensor(hp.CLIP_MEAN, dtype=torch.float32) * 255.0).tolist()
+                std = (torch.tensor(hp.CLIP_STD, dtype=torch.float32) * 255.0).tolist()
+                lib.call("vr2_patchify_u8", data, n, hh, ww, pl.d_gather, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), dst,
+                         dst.stride(0), pl.n_patches, v.patch_size, v.temporal_patch_size, v.spatial_merge_size, Kp, self.s)
+            else:
+                lib.call("vr2_cast_rows_f32_bf16", data, data.stride(0), pl.d_gather, dst, dst.stride(0), pl.n_patches, v.patch_dim, Kp, self.s)
+            singles.append(pl)
+            row += pl.n_patches
+        out = self._vision_blocks(pl_all, a0).clone()          # the combined window order is clip after clip
+        res, tok, ci = [], 0, 0
+        for k in per_prompt:
+            if k == 0:
+                res.append((None, None))
+                continue
+            pl = singles[ci] if k == 1 else self.vision_plan(grids[ci:ci + k])
+            res.append((out[tok:tok + pl.n_tokens], pl))
+            tok += pl.n_tokens
+            ci += k
+        return res
+
     def _vision_blocks(self, pl, a0):
         """patch-embed GEMM input a0 bf16 [P][Kpad] (window order) -> merged video tokens (K1-K7)"""
         v = self.cfg.vision
@@ -283,9 +348,10 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ LM building blocks
-    def _lm_rows(self, W: Params, x, T, cos, sin, work, kA, vA, k_own, v_own, own_row0, tag):
+    def _lm_rows(self, W: Params, x, T, cos, sin, work, kA, vA, k_own, v_own, own_row0, tag, seg=None):
         """All decoder layers over T rows (prefill or teacher-forced scoring).  k_own/v_own: per-layer [L][rows][nkv*hd]
-        caches (prefill) or a single [rows][nkv*hd] scratch reused by every layer (scoring)."""
+        caches (prefill) or a single [rows][nkv*hd] scratch reused by every layer (scoring).  seg = (rows per prompt, slot
+        stride in rows): batched prefill, the K/V rows of prompt p go to slot p (vr2_rope_qkv_seg) and k_own[l] is slot 0."""
         t = self.cfg.text
         H, hd, nq, nkv, I = t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size
         nqkv = (nq + 2 * nkv) * hd
@@ -302,7 +368,11 @@ class Engine:
             va = vo if vA is None else vA[l]
             self._norm(x, W[f"l{l}.ln1"], xn, T, H, t.rms_norm_eps)
             self._gemm(xn, W, f"l{l}.qkv_w", W[f"l{l}.qkv_b"], qkv, T, EPI_F32)
-            lib.call("vr2_rope_qkv", qkv, qkv.stride(0), cos, sin, T, nq, nkv, hd, qb, qb.stride(0), ko, vo, ko.stride(0), own_row0, self.s)
+            if seg is None:
+                lib.call("vr2_rope_qkv", qkv, qkv.stride(0), cos, sin, T, nq, nkv, hd, qb, qb.stride(0), ko, vo, ko.stride(0), own_row0, self.s)
+            else:
+                lib.call("vr2_rope_qkv_seg", qkv, qkv.stride(0), cos, sin, T, nq, nkv, hd, qb, qb.stride(0), ko, vo, ko.stride(0),
+                         seg[0], seg[1], self.s)
             lib.call("vr2_attn_tok", work, work.shape[0], qb, qb.stride(0), ka, va, ko, vo, ko.stride(0), att,
                      att.stride(0), nq, t.group, hd, scale, None, self.s)
             self._gemm(att, W, f"l{l}.o_w", None, x, T, EPI_ADD_F32)
@@ -362,6 +432,76 @@ class Engine:
         logits = self.buf(tag + ".plogits" + slot, (1, t.vocab_size), torch.float32)
         self._logits_rows(W, x[S - 1:S], 1, logits)
         return PromptState(n_prompt=S, rope_delta=delta, prefix_k=pk, prefix_v=pv, last_hidden=last, last_logits=logits)
+
+    @_on_stream
+    def prefill_batch(self, W: Params, prompts, slots, tag="pol", max_rows=36864):
+        """Prompt prefill of several prompts in ONE row space (M = sum of rows: the decoder GEMMs run on full tiles instead of
+        one ~1k-row prompt at a time).  prompts: list of (input_ids, video_embeds, plan, second_per_grid_ts) as for prefill();
+        slots: Engine.prefix_slots(...) -- prompt p's K/V go to slots[p].  Rows per prompt = the longest prompt of the batch
+        (shorter ones are padded with pad tokens after their last token: causal attention never looks ahead, the padded rows
+        are never read).  -> [PromptState]; long batches are cut into pieces of <= max_rows rows."""
+        cfg, t = self.cfg, self.cfg.text
+        H, hd, nkv, L, V = t.hidden_size, t.head_dim, t.num_key_value_heads, t.num_hidden_layers, t.vocab_size
+        idss = [np.asarray(p[0], dtype=np.int64).reshape(-1) for p in prompts]
+        rp = max(len(i) for i in idss)
+        per = max(1, max_rows // rp)
+        if len(prompts) > per:
+            out = []
+            for c0 in range(0, len(prompts), per):
+                out += self.prefill_batch(W, prompts[c0:c0 + per], slots[c0:c0 + per], tag=tag, max_rows=max_rows)
+            return out
+        P = len(prompts)
+        k0, v0 = slots[0]
+        kvw = nkv * hd
+        if k0.stride(2) != 1 or k0.stride(1) != kvw or k0.shape[1] < rp:
+            raise ValueError("prefill_batch needs cache slots from Engine.prefix_slots with room for the longest prompt")
+        gstride = 0
+        if P > 1:
+            gstride = (slots[1][0].data_ptr() - k0.data_ptr()) // (k0.element_size() * kvw)       # slot stride in rows
+            for p_, (sk, _) in enumerate(slots):
+                if sk.data_ptr() != k0.data_ptr() + p_ * gstride * kvw * k0.element_size():
+                    raise ValueError("prefill_batch needs cache slots with a uniform stride (Engine.prefix_slots)")
+        lstride = k0.stride(0) // kvw                           # rows between layers inside a slot
+        T = P * rp
+        ids_all = np.full((P, rp), cfg.pad_token_id, dtype=np.int64)
+        pos_all = np.zeros((3, P, rp), dtype=np.int64)
+        deltas, works = [], []
+        for p_, ((_, emb, plan, sec), ids) in enumerate(zip(prompts, idss)):
+            S = len(ids)
+            ids_all[p_, :S] = ids
+            grids = [] if plan is None else plan.grid_thw
+            pos, delta = ri.rope_index_1seq(ids, cfg.video_token_id, cfg.image_token_id, grids, sec,
+                                            merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
+            pos_all[:, p_, :S] = pos
+            deltas.append(delta)
+            # queries = this prompt's rows of the batch; keys = its own cache slot, causal (row index relative to slot 0 of the layer)
+            works.append(vp.causal_work(S, p_ * rp, 0, 0, p_ * gstride))
+        x = self.buf(tag + ".bx", (T, H), torch.float32)
+        d_ids = _i32(ids_all.reshape(-1), self.device)
+        lib.call("vr2_embed_rows", d_ids, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, self.s)
+        for p_, ((_, emb, plan, _), ids) in enumerate(zip(prompts, idss)):
+            vid_pos = np.flatnonzero(ids == cfg.video_token_id)
+            if emb is not None:
+                if vid_pos.shape[0] != emb.shape[0]:
+                    raise ValueError(f"Video features and video tokens do not match, tokens: {vid_pos.shape[0]}, features: {emb.shape[0]}")
+                dst = _i32(p_ * rp + vid_pos[plan.window_index], self.device)
+                lib.call("vr2_scatter_rows_f32", emb, emb.stride(0), dst, x, x.stride(0), vid_pos.shape[0], H, self.s)
+            elif vid_pos.shape[0]:
+                raise ValueError("prompt has video tokens but no video features were given")
+        cos = self.buf(tag + ".bcos", (T, hd // 2), torch.float32)
+        sin = self.buf(tag + ".bsin", (T, hd // 2), torch.float32)
+        lib.call("vr2_mrope_table", _i32(pos_all.reshape(3, T), self.device), T, self.inv_freq, self.section, cos, sin, hd, self.s)
+        work = _i32(np.concatenate(works, 0), self.device)
+        # per-layer K/V base = layer l of slot 0: [L][rows][kv] view with the slot's own layer stride
+        kl = torch.as_strided(k0, (L, lstride, kvw), (lstride * kvw, kvw, 1))
+        vl = torch.as_strided(v0, (L, lstride, kvw), (lstride * kvw, kvw, 1))
+        self._lm_rows(W, x, T, cos, sin, work, None, None, kl, vl, 0, tag + ".b", seg=(rp, max(gstride, rp)))
+        last_rows = torch.as_tensor([p_ * rp + len(ids) - 1 for p_, ids in enumerate(idss)], device=self.device)
+        lasts = torch.index_select(x, 0, last_rows)             # owned by the returned states (a batch may be cut into pieces)
+        logits = torch.empty((P, V), dtype=torch.float32, device=self.device)
+        self._logits_rows(W, lasts, P, logits)
+        return [PromptState(n_prompt=len(ids), rope_delta=deltas[p_], prefix_k=slots[p_][0], prefix_v=slots[p_][1],
+                            last_hidden=lasts[p_:p_ + 1], last_logits=logits[p_:p_ + 1]) for p_, ids in enumerate(idss)]
 
     # ------------------------------------------------------------------ decode (K13, K14)
     def prefix_slots(self, n_groups, max_prompt, tag="pol"):

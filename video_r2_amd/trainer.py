@@ -127,29 +127,23 @@ class QwenGRPOTrainer:
     # ------------------------------------------------------------------ rollout + scoring for this rank's prompt groups
     MAX_DECODE_ROWS = 128      # sequences per decode weight pass (Engine.decode): G * groups-per-chunk stays below it
 
-    def _encode(self, pi):
-        eng = self.model.engine
+    def _clips(self, pi):
+        """the clips of one processed example as Engine.encode_videos wants them"""
         vids = pi.get("videos")
-        if vids:
-            if len(vids) == 1:                       # one clip: resize + rescale + normalise + patchify + gather on the device
-                frames, dims = vids[0]
-                emb, plan, _ = eng.encode_frames(frames, resize_to=dims)
-                return emb, plan
-            from .host import processor as hp        # several clips in one prompt: device resize, processor layout per clip
-            pxs, grids = [], []
-            v = self.model.cfg.vision
-            for frames, dims in vids:
-                fr = eng.resize_frames(frames, dims[0], dims[1])
-                px, grid = hp.patchify(hp.normalize_frames(fr), v.patch_size, v.spatial_merge_size, v.temporal_patch_size)
-                pxs.append(px); grids.append(grid)
-            return eng.encode_video(torch.cat(pxs, 0), grids)
-        if pi.get("video_frames_u8") is not None:
-            # post-resize uint8 frames [N,3,H,W]: rescale + normalise + patchify run on the device (Engine.encode_frames)
-            emb, plan, _ = eng.encode_frames(pi["video_frames_u8"])
-            return emb, plan
-        if pi.get("pixel_values_videos") is not None:
-            return eng.encode_video(pi["pixel_values_videos"], pi["video_grid_thw"])
-        return None, None
+        if vids:                                     # uint8 clips: resize + rescale + normalise + patchify + gather on the device
+            return [dict(frames_u8=frames, resize_to=dims) for frames, dims in vids]
+        if pi.get("video_frames_u8") is not None:    # already resized
+            return [dict(frames_u8=pi["video_frames_u8"], resize_to=None)]
+        if pi.get("pixel_values_videos") is not None:   # host-processed, as the HF processor returns them (one row block per grid)
+            px = pi["pixel_values_videos"]
+            grids = np.asarray(pi["video_grid_thw"].cpu() if torch.is_tensor(pi["video_grid_thw"]) else pi["video_grid_thw"]).reshape(-1, 3)
+            out, at = [], 0
+            for g in grids:
+                n = int(g[0] * g[1] * g[2])
+                out.append(dict(pixel_values=px[at:at + n], grid=tuple(int(x) for x in g)))
+                at += n
+            return out
+        return []
 
     def _rollout_all(self, examples, seed, processed=None):
         """Rollouts of all of this rank's prompt groups.  The groups are encoded + prefilled one by one into shared-stride prefix
@@ -167,15 +161,12 @@ class QwenGRPOTrainer:
             chunk = examples[c0:c0 + per]
             pis = processed[c0:c0 + per] if processed is not None else [self.processing_fn(ex) for ex in chunk]
             idss = [np.asarray(pi["input_ids"]).reshape(-1)[-a.max_prompt_length:] for pi in pis]
-            slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="pol") if len(chunk) > 1 else [None]
-            states, encs = [], []
-            for p_, (pi, ids) in enumerate(zip(pis, idss)):
-                emb, plan = self._encode(pi)
-                if emb is not None and len(examples) > 1:
-                    emb = emb.clone()                              # the ViT output workspace is reused by the next group
-                sec = pi.get("second_per_grid_ts")
-                encs.append((emb, plan, sec))
-                states.append(eng.prefill(m.text, ids, emb, plan, sec, tag="pol", prefix_out=slots[p_]))
+            # the chunk's clips go through the vision tower in ONE pass and its prompts through ONE prefill (full GEMM tiles)
+            slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="pol")
+            clips = [self._clips(pi) for pi in pis]
+            enc = eng.encode_videos([c for cl in clips for c in cl], per_prompt=[len(cl) for cl in clips])
+            encs = [(emb, plan, pi.get("second_per_grid_ts")) for (emb, plan), pi in zip(enc, pis)]
+            states = eng.prefill_batch(m.text, [(ids, emb, plan, sec) for ids, (emb, plan, sec) in zip(idss, encs)], slots, tag="pol")
             toks_all, _ = eng.decode(m.text, states if len(states) > 1 else states[0], G, a.max_completion_length,
                                      temperature=a.temperature, top_k=a.top_k, seed=seed + 7919 * c0,
                                      eos_token_id=m.cfg.eos_token_id)
@@ -195,10 +186,12 @@ class QwenGRPOTrainer:
                         from concurrent.futures import ThreadPoolExecutor
                         self._reward_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="vr2-rewards")
                     pending = self._reward_pool.submit(self._rewards, examples, groups)
-            for ro in new:   # scoring while the chunk's prefix caches are still in place
+            if self.beta != 0.0:     # the reference model's prompt prefill, batched the same way
+                ref_slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="ref")
+                ref_states = eng.prefill_batch(self.ref_params, [(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"]) for ro in new], ref_slots, tag="ref")
+            for k_, ro in enumerate(new):   # scoring while the chunk's prefix caches are still in place
                 if self.beta != 0.0:
-                    st_ref = eng.prefill(self.ref_params, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], tag="ref")
-                    ro["ref_logps"] = eng.score(self.ref_params, st_ref, ro["completion_ids"], a.temperature, tag="ref")
+                    ro["ref_logps"] = eng.score(self.ref_params, ref_states[k_], ro["completion_ids"], a.temperature, tag="ref")
                     if len(examples) > 1:
                         ro["ref_logps"] = ro["ref_logps"].clone()  # the scoring output is a reused workspace
                 if not self.update:

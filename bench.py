@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 PMC_TRAFFIC_W8_128 = 148.3e6  # fp8 weights, 128 rows (profiles/r01_pmc_gemv_gateup_64rows.md, third table)
 # HBM bytes per launch by (projection, rows), rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE): filled from profiles/*.md
-PMC_TRAFFIC = {("gu", 8): 273.2e6}
+PMC_TRAFFIC = {("gu", 8): 273.2e6, ("gu", 128): 285.3e6, ("down", 128): 189.5e6}   # profiles/r01_pmc_gemv_gateup.md, profiles/r02_gemv_ring.md
 
 
 def parse():

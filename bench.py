@@ -51,9 +51,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-update", action="store_true", help="rollout + scoring + loss only (no backward / optimiser)")
-    p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
-                   help="fp8: the decode GEMVs stream per-channel e4m3 copies of the LM weights (BASELINE config 5); prefill, "
-                        "scoring and training stay bf16; the copies are re-quantised after every optimiser step (timed)")
+    p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8", "fp8w"],
+                   help="fp8 (BASELINE config 5): the decode GEMVs stream per-channel e4m3 copies of the LM weights and, above 16 "
+                        "rows, per-row e4m3 activations on the fp8 MFMA; fp8w: weight-only (bf16 activations, bf16 MFMA: round 1). "
+                        "Prefill, scoring and training stay bf16; the copies are re-quantised after every optimiser step (timed)")
     p.add_argument("--launch-check", action="store_true",
                    help="rehearse the N-rank launch only: process group, barrier, max-over-ranks timing and the JSON line, no "
                         "engine work (runs without a GPU; tests/test_bench_launch.py)")
@@ -240,10 +241,11 @@ def main():
     del sd
     torch.cuda.empty_cache()
     eng = Engine(cfg, vis, pol, device=device)
-    fp8 = a.decode_weights == "fp8"
+    fp8 = a.decode_weights in ("fp8", "fp8w")
     if fp8:
         W.add_fp8_decode_copies(pol)
         eng.decode_fp8 = True
+        eng.decode_fp8_act = a.decode_weights == "fp8"
     from video_r2_amd.train import Trainer
     upd = None if a.no_update else Trainer(eng, pol)       # fp32 masters + Adam moments + transposed packed copies
     P = a.prompts_per_gpu
@@ -398,9 +400,15 @@ def main():
         reps = 3
         e0, e1 = ev(), ev()
         fp8r = fp8 and NG <= eng.decode_fp8_max_rows         # above that the engine decodes with the bf16 kernels
+        a8 = fp8r and eng._a8w8(pol, "l0.gu_w", NG)           # fp8 activations on the fp8 MFMA (> 16 rows)
+        if a8:
+            xq8, xqs = eng._quant(xn, NG, H)                  # quantised once, outside the timed launches
 
         def gu(l):
-            if fp8r:
+            if a8:
+                q8, sc = pol.f8[f"l{l}.gu_w"]
+                lib.call("vr2_gemv_gateup_silu_a8w8", xq8, xq8.stride(0), xqs, NG, q8, sc, I, H, act, act.stride(0), eng.s)
+            elif fp8r:
                 q8, sc = pol.f8[f"l{l}.gu_w"]
                 lib.call("vr2_gemv_gateup_silu_w8", xn, xn.stride(0), NG, q8, sc, I, H, act, act.stride(0), eng.s)
             else:
@@ -414,16 +422,18 @@ def main():
         L.vr2_event_record(e1, ctypes.c_void_p(eng.s))
         eng.sync()
         k_ms = elapsed(e0, e1) / (reps * Lh)
-        alg = 2 * I * H * (1 if fp8r else 2) + (2 * I * 4 if fp8r else 0) + NG * H * 2 + NG * I * 2
+        alg = 2 * I * H * (1 if fp8r else 2) + (2 * I * 4 if fp8r else 0) + NG * H * (1 if a8 else 2) + NG * I * 2
         ach = alg / (k_ms * 1e-3) / 1e9
         mbs = 2 if NG <= 32 else 4 if NG <= 64 else 8
-        if fp8r:
+        if a8:
+            kname = "gemv_ring8_kernel<1, %d, 1> (fp8 activations x fp8 weights, v_mfma_f32_16x16x32_fp8_fp8)" % mbs
+        elif fp8r:
             kname = "gemv16_w8_kernel<1>" if NG <= 16 else ("gemv_lds_w8_kernel<1, %d>" % mbs if NG <= 64 else "gemv_lds_w8s_kernel<1, 8, 1>")
         else:
             kname = "gemv16_kernel<1, 1, 4>" if NG <= 16 else "gemv_ring_kernel<1, %d, 1, 0>" % mbs
         # HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/r02_pmc_gemv_ring.md
         # (7B shape, bf16 weights; 8 rows: profiles/r01_pmc_gemv_gateup.md)
-        traffic = PMC_TRAFFIC.get(("gu", NG)) if (a.model == "7b" and not fp8r) else (PMC_TRAFFIC_W8_128 if (a.model == "7b" and fp8r and NG == 128) else None)
+        traffic = PMC_TRAFFIC.get(("gu", NG)) if (a.model == "7b" and not fp8r) else (PMC_TRAFFIC_W8_128 if (a.model == "7b" and fp8r and not a8 and NG == 128) else None)
         roof = {"bound": "hbm", "kernel": kname + " (decode gate/up GEMV + SiLU*mul, %d rows)" % NG, "achieved": ach,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_us": k_ms * 1e3, "algorithmic_bytes_per_launch": alg}
@@ -483,7 +493,8 @@ def main():
             "rccl_ranks": world if (world > 1 and backend == "nccl") else 0, "dist_backend": backend if world > 1 else None,
             "rank_ms_per_step": [t / a.steps * 1e3 for t in rank_dt],
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not fp8 else "bf16 (decode weights fp8 e4m3, per-channel scales)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not fp8 else ("bf16 (decode: fp8 e4m3 weights per channel x fp8 activations per row on the fp8 MFMA)" if a.decode_weights == "fp8"
+                                                                            else "bf16 (decode weights fp8 e4m3, per-channel scales)"), "data": "synthetic",
             "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} {a.frames} frames 224^2, G={G}, {C} new tokens, {P} prompt group(s) per GPU per step",
                        "prompts_per_gpu_per_step": P,
                        "prompt_tokens": 32 * a.frames + 64, "weights": "random-init seed 0, bf16",

@@ -63,12 +63,26 @@ int vr2_gemv_w8(const void* x_bf16, int64_t ldx, int64_t M, const void* W_packed
 int vr2_gemv_gateup_silu_w8(const void* x_bf16, int64_t ldx, int64_t M, const void* W_packed_fp8, const void* scale_f32, int64_t I,
                             int64_t K, void* act_bf16, int64_t ldo, void* stream);
 
+/* BASELINE config 5 on the fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8): fp8 ACTIVATIONS x fp8 weights for 16 < M <= 128 decode rows.
+ * vr2_quant_rows_fp8: x bf16 [M][K] -> e4m3 bytes [M][ldq] (K zero-padded to 64) + scale[m] = amax / 448; inside every 64-k block
+ * the 16-byte slot s holds k = 8s..8s+7 then k = 32+8s..32+8s+7 (two MFMA k-steps per 16-byte fragment read).  The two GEMVs
+ * take that buffer + scales and the weight copies of vr2_gemv_w8; out = (sum_k q_x q_w) * scale_x[m] * scale_w[n].  K % 128 == 0. */
+int vr2_quant_rows_fp8(const void* x_bf16, int64_t ldx, int64_t M, int64_t K, void* q_fp8, int64_t ldq, void* scale_f32, void* stream);
+int vr2_gemv_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64_t M, const void* W_packed_fp8, const void* wscale_f32,
+                  int64_t N, int64_t K, void* out_f32, int64_t split_stride, int64_t ldo, int nsplit, void* stream);
+int vr2_gemv_gateup_silu_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64_t M, const void* W_packed_fp8,
+                              const void* wscale_f32, int64_t I, int64_t K, void* act_bf16, int64_t ldo, void* stream);
+
 /* ---- row kernels ------------------------------------------------------------------------------------------- */
 /* x (+)= bias + sum_s partial[s] ; y = bf16(rmsnorm(x) * w).  Qwen2_5_VLRMSNorm HF:65-79 (K2, K10) fused with the
  * residual add of the preceding projection.  partial / bias / y may be NULL. */
 int vr2_add_rmsnorm(void* x_f32, int64_t ldx, const void* partial_f32, int64_t split_stride, int64_t ldp, int nsplit,
                     const void* bias_f32, const void* w_f32, void* y_bf16, int64_t ldy, int64_t M, int64_t H, float eps,
                     void* stream);
+/* the same with vr2_quant_rows_fp8 fused in: besides y, the row's e4m3 bytes (fragment order) and scale.  H % 64 == 0, H <= 4096 */
+int vr2_add_rmsnorm_q8(void* x_f32, int64_t ldx, const void* partial_f32, int64_t split_stride, int64_t ldp, int nsplit,
+                       const void* bias_f32, const void* w_f32, void* y_bf16, int64_t ldy, int64_t M, int64_t H, float eps,
+                       void* q_fp8, int64_t ldq, void* qscale_f32, void* stream);
 /* dst[m][0:Kpad] = bf16(src[row_idx ? row_idx[m] : m][0:K]) zero padded: pixel_values cast + window permutation
  * gather (HF :436-439, K6) in one pass. */
 int vr2_cast_rows_f32_bf16(const void* src_f32, int64_t lds, const void* row_idx_i32, void* dst_bf16, int64_t ldd,

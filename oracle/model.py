@@ -164,6 +164,16 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def fp8_qdq_rows(x):
+    """Per-row e4m3 quantise-dequantise of bf16-rounded activations: what vr2_quant_rows_fp8 + the a8w8 GEMVs see (BASELINE
+    config 5 with fp8 activations): scale = amax / 448 over the last dim, round to nearest even, x ~= q * scale."""
+    x = _bf16(x.float())
+    am = x.abs().amax(dim=-1, keepdim=True)
+    inv = torch.where(am > 0, torch.full_like(am, 448.0) / am, torch.ones_like(am))   # true division, as the kernel's 448.0f / amax
+    sc = torch.where(am > 0, am / 448.0, torch.ones_like(am))
+    return (x * inv).to(torch.float8_e4m3fn).float() * sc
+
+
 def rms_norm(x, w, eps, rd=_ident):
     """HF:65-79 (variance in fp32, cast back to the input dtype, then times weight)."""
     x = x.float()
@@ -241,11 +251,12 @@ def mrope_cos_sin(cfg: Cfg, position_ids):
     return cos, sin
 
 
-def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv_cache=None, emulate_bf16=False):
+def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv_cache=None, emulate_bf16=False, act_quant=None):
     """HF:790-872 + decoder layers :641-757.  inputs_embeds [B,S,H]; position_ids [3,B,S];
     attention_mask [B, S_total] over cached+new keys (1 = attend).  kv_cache: list of (k,v) [B,Hkv,T,hd]
     (updated in place when given).  Returns final-normed hidden [B,S,H]."""
     rd = _bf16 if emulate_bf16 else _ident
+    aq = act_quant if act_quant is not None else _ident       # applied to the input of every projection (config 5, fp8 activations)
     t = cfg.text
     B, S, H = inputs_embeds.shape
     nh, nkv = t.num_attention_heads, t.num_key_value_heads
@@ -263,7 +274,7 @@ def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv
     x = rd(inputs_embeds.float())
     for li in range(t.num_hidden_layers):
         p = f"model.layers.{li}."
-        h = rms_norm(x, w[p + "input_layernorm.weight"], t.rms_norm_eps, rd)
+        h = aq(rms_norm(x, w[p + "input_layernorm.weight"], t.rms_norm_eps, rd))
         q = rd(h @ w[p + "self_attn.q_proj.weight"].t() + w[p + "self_attn.q_proj.bias"]).view(B, S, nh, hd).transpose(1, 2)
         k = rd(h @ w[p + "self_attn.k_proj.weight"].t() + w[p + "self_attn.k_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
         v = rd(h @ w[p + "self_attn.v_proj.weight"].t() + w[p + "self_attn.v_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
@@ -280,10 +291,10 @@ def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv
         att = att.softmax(-1)
         att = rd(torch.nan_to_num(att))  # fully-masked (padding) query rows
         o = rd(att @ vr).transpose(1, 2).reshape(B, S, nh * hd)
-        x = rd(x + rd(o @ w[p + "self_attn.o_proj.weight"].t()))
-        h = rms_norm(x, w[p + "post_attention_layernorm.weight"], t.rms_norm_eps, rd)
+        x = rd(x + rd(aq(o) @ w[p + "self_attn.o_proj.weight"].t()))
+        h = aq(rms_norm(x, w[p + "post_attention_layernorm.weight"], t.rms_norm_eps, rd))
         g = rd(rd(F.silu(rd(h @ w[p + "mlp.gate_proj.weight"].t()))) * rd(h @ w[p + "mlp.up_proj.weight"].t()))
-        x = rd(x + rd(g @ w[p + "mlp.down_proj.weight"].t()))
+        x = rd(x + rd(aq(g) @ w[p + "mlp.down_proj.weight"].t()))
     return rms_norm(x, w["model.norm.weight"], t.rms_norm_eps, rd)
 
 

@@ -6,6 +6,7 @@ from video_r2_amd import lib, weights as W
 from video_r2_amd.engine import Engine
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+MODE = sys.argv[3] if len(sys.argv) > 3 else "bf16"          # bf16 | fp8 (weights + activations) | fp8w (weight-only)
 lib.load()
 device = "cuda:0"
 cfg = model_cfg("7b")
@@ -13,6 +14,9 @@ sd = W.random_state_dict(cfg, seed=0, device=device)
 vis = W.build_vision(cfg, sd, device); pol = W.build_text(cfg, sd, device)
 del sd
 eng = Engine(cfg, vis, pol, device=device)
+if MODE != "bf16":
+    W.add_fp8_decode_copies(pol)
+    eng.decode_fp8, eng.decode_fp8_act = True, MODE == "fp8"
 prompts = [synth_prompt(cfg, 32, i, device) for i in range(P)]
 slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="pol")
 states = []
@@ -23,4 +27,4 @@ for rep in range(2):
     eng.sync(); t0 = time.perf_counter()
     toks, _ = eng.decode(pol, states, 8, C, temperature=0.9, top_k=50, seed=rep, eos_token_id=None)
     eng.sync(); dt = time.perf_counter() - t0
-    print(f"P={P} rows={8*P} C={C}: {dt*1e3/C:.3f} ms/token", flush=True)
+    print(f"P={P} rows={8*P} C={C} {MODE}: {dt*1e3/C:.3f} ms/token", flush=True)

@@ -2,10 +2,10 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 P=${1:-8}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dec -- python profiles/src/decode_only.py $P ${2:-256} > gpurun_out/dec$P.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dec -- python3 profiles/src/decode_only.py $P ${2:-256} ${3:-bf16} > gpurun_out/dec$P.log 2>&1
 grep "ms/token" gpurun_out/dec$P.log
 f=$(find gpurun_out/prof_dec -name "*kernel_stats.csv" | head -1)
-python - "$f" <<'PY'
+python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(int(r['TotalDurationNs']) for r in rows)

@@ -522,3 +522,101 @@ def test_gemv_fp8_weights_exact_and_random(dev, M):
     ref = torch.nn.functional.silu(pre[:, :, 0]) * pre[:, :, 1]
     assert (act.float().cpu().view(M, I // 16, 16) - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-4
     assert (Wd - Wint).abs().max().item() <= 2 ** -4 * Wint.abs().max().item()      # e4m3: 3 mantissa bits
+
+
+def _deinterleave_fp8_rows(q8, K):
+    """bytes in vr2_quant_rows_fp8 order -> natural k order: slot s of a 64-k block holds k 8s..8s+7 then 32+8s..32+8s+7"""
+    M, kp = q8.shape[0], (K + 63) // 64 * 64
+    return q8[:, :kp].reshape(M, kp // 64, 4, 2, 8).permute(0, 1, 3, 2, 4).reshape(M, kp)[:, :K]
+
+
+@pytest.mark.parametrize("M,K", [(5, 200), (33, 1152), (128, 3584)])
+def test_quant_rows_fp8_matches_torch_e4m3(dev, M, K):
+    """per-row e4m3 quantisation of bf16 activations (BASELINE config 5, fp8 activations): bytes equal torch's
+    float8_e4m3fn rounding of x * (448 / amax) in the kernel's fragment order, scale = amax / 448, zero rows and the zero
+    padding of the last 64-k block included"""
+    g = torch.Generator().manual_seed(M + K)
+    x = (3 * torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    x[min(2, M - 1)] = 0                                                   # an all-zero row: scale 1, bytes 0
+    kp = (K + 127) // 128 * 128
+    q8 = torch.full((M, kp), 0xAA, dtype=torch.uint8, device=dev)
+    sc = torch.zeros(M, device=dev)
+    lib.call("vr2_quant_rows_fp8", x.to(dev), K, M, K, q8, kp, sc, S())
+    torch.cuda.synchronize()
+    xf = x.float()
+    am = xf.abs().amax(1, keepdim=True)
+    inv = torch.where(am > 0, torch.full_like(am, 448.0) / am, torch.ones_like(am))   # a true division (scalar / tensor is reciprocal * scalar in torch)
+    want = (xf * inv).to(torch.float8_e4m3fn).view(torch.uint8)
+    got = _deinterleave_fp8_rows(q8.cpu(), K)
+    assert torch.equal(got, want)
+    assert torch.equal(sc.cpu(), torch.where(am > 0, am / 448.0, torch.ones_like(am))[:, 0])
+    k64 = (K + 63) // 64 * 64
+    assert torch.all(_deinterleave_fp8_rows(q8.cpu(), k64)[:, K:] == 0)
+
+
+@pytest.mark.parametrize("M", [20, 64, 128])
+def test_gemv_fp8_activations_on_the_fp8_mfma(dev, M):
+    """vr2_gemv_a8w8 / vr2_gemv_gateup_silu_a8w8 (v_mfma_f32_16x16x32_fp8_fp8): against the matmul of the DEQUANTISED operands in
+    float64 -- the products of two e4m3 values are exact in fp32, only the summation order differs -- for a ragged N, split-K
+    and the fused SiLU*mul epilogue; plus an exact-integer case"""
+    from video_r2_amd.weights import dequantize_rows_fp8, interleave_gate_up, pack_tiles_fp8, quantize_rows_fp8
+    g = torch.Generator().manual_seed(100 + M)
+    N, K = 424, 1152
+    W = torch.randn(N, K, generator=g) * 0.05
+    x = (2 * torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    qw, sw = quantize_rows_fp8(W)
+    Wd = dequantize_rows_fp8(qw, sw).double()
+    q8 = torch.zeros((M, K), dtype=torch.uint8, device=dev)
+    xs = torch.zeros(M, device=dev)
+    lib.call("vr2_quant_rows_fp8", x.to(dev), K, M, K, q8, K, xs, S())
+    xd = (_deinterleave_fp8_rows(q8.cpu(), K).view(torch.float8_e4m3fn).float() * xs.cpu()[:, None]).double()
+    Wp, swd = pack_tiles_fp8(qw.to(dev)), torch.cat([sw, torch.ones((-N) % 16)]).to(dev)
+    for nsplit in (1, 3):
+        out = torch.zeros(nsplit, M, N, device=dev)
+        lib.call("vr2_gemv_a8w8", q8, K, xs, M, Wp, swd, N, K, out, out.stride(0) if nsplit > 1 else 0, N, nsplit, S())
+        got = out.sum(0).cpu().double()
+        want = xd @ Wd.t()
+        assert (got - want).abs().max() <= 5e-5 * want.abs().max(), (nsplit, (got - want).abs().max())   # fp32 sums of 1152 exact products, two orders
+    # gate/up + SiLU*mul: I = 208 output columns from 2 x 208 interleaved weight rows
+    I = 208
+    Wg, Wu = torch.randn(I, K, generator=g) * 0.05, torch.randn(I, K, generator=g) * 0.05
+    qg, sg = quantize_rows_fp8(Wg)
+    qu, su = quantize_rows_fp8(Wu)
+    qi, si = interleave_gate_up(qg.to(dev), qu.to(dev)), interleave_gate_up(sg.to(dev), su.to(dev)).contiguous()
+    act = torch.zeros(M, I, dtype=torch.bfloat16, device=dev)
+    lib.call("vr2_gemv_gateup_silu_a8w8", q8, K, xs, M, pack_tiles_fp8(qi), si, I, K, act, I, S())
+    gd, ud = xd @ dequantize_rows_fp8(qg, sg).double().t(), xd @ dequantize_rows_fp8(qu, su).double().t()
+    want = (torch.nn.functional.silu(gd) * ud)
+    assert rel_err(act.float().cpu().numpy(), want.numpy(), floor=want.abs().max().item() * 1e-2).max() < 1e-2   # one bf16 rounding
+    # exact integers: e4m3 holds -8..8 exactly, power-of-two scales, every partial sum an integer below 2^24
+    Wi = torch.randint(-8, 9, (N, K), generator=g).float() * 0.25
+    xi = torch.randint(-4, 5, (M, K), generator=g).float()
+    xi[:, 0] = 4.0                                                        # amax 4 -> scale 4/448 = 2^-7 * ... (not a power of two: check via dequant)
+    qwi, swi = quantize_rows_fp8(Wi)
+    lib.call("vr2_quant_rows_fp8", xi.to(torch.bfloat16).to(dev), K, M, K, q8, K, xs, S())
+    out = torch.zeros(1, M, N, device=dev)
+    lib.call("vr2_gemv_a8w8", q8, K, xs, M, pack_tiles_fp8(qwi.to(dev)), torch.cat([swi, torch.ones((-N) % 16)]).to(dev), N, K, out, 0, N, 1, S())
+    xq = (_deinterleave_fp8_rows(q8.cpu(), K).view(torch.float8_e4m3fn).float() * xs.cpu()[:, None]).double()
+    want = xq @ dequantize_rows_fp8(qwi, swi).double().t()
+    assert (out[0].cpu().double() - want).abs().max() <= 1e-6 * want.abs().max()   # integer sums x two fp32 scale factors
+
+
+def test_add_rmsnorm_with_fused_fp8_quantisation(dev):
+    """vr2_add_rmsnorm_q8 = vr2_add_rmsnorm followed by vr2_quant_rows_fp8 on its bf16 output, byte for byte (split-K slabs + bias)"""
+    M, H, ns = 37, 3584, 3
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(M, H, generator=g)
+    part = (0.3 * torch.randn(ns, M, H, generator=g)).to(dev)
+    bias = (0.1 * torch.randn(H, generator=g)).to(dev)
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    xa, xb = x0.clone().to(dev), x0.clone().to(dev)
+    ya = torch.zeros(M, H, dtype=torch.bfloat16, device=dev)
+    yb = torch.zeros_like(ya)
+    lib.call("vr2_add_rmsnorm", xa, H, part, part.stride(0), part.stride(1), ns, bias, w, ya, H, M, H, 1e-6, S())
+    qa, sa = torch.zeros((M, H), dtype=torch.uint8, device=dev), torch.zeros(M, device=dev)
+    lib.call("vr2_quant_rows_fp8", ya, H, M, H, qa, H, sa, S())
+    qb, sb = torch.full((M, H + 128), 7, dtype=torch.uint8, device=dev), torch.zeros(M, device=dev)
+    lib.call("vr2_add_rmsnorm_q8", xb, H, part, part.stride(0), part.stride(1), ns, bias, w, yb, H, M, H, 1e-6, qb, qb.stride(0), sb, S())
+    torch.cuda.synchronize()
+    assert torch.equal(xa, xb) and torch.equal(ya, yb) and torch.equal(sa, sb)
+    assert torch.equal(qa, qb[:, :H]) and bool((qb[:, H:] == 7).all())

@@ -30,7 +30,8 @@ template <bool REG>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* __restrict__ x, long ldx, const float* __restrict__ partial,
                                                           long split_stride, long ldp, int nsplit,
                                                           const float* __restrict__ bias, const float* __restrict__ w,
-                                                          bf16* __restrict__ y, long ldy, int H, float eps) {
+                                                          bf16* __restrict__ y, long ldy, int H, float eps,
+                                                          unsigned char* __restrict__ q8, long ldq, float* __restrict__ qscale) {
   __shared__ float scratch[4];
   const int m = blockIdx.x;
   float* xr = x + (long)m * ldx;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* __restrict__ x,
     if (!y) return;
     const float inv = rsqrtf(ss / (float)H + eps);
     bf16* yr = y + (long)m * ldy;
+    float am = 0.f;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int i = threadIdx.x * 4 + it * 1024;
@@ -92,6 +94,27 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* __restrict__ x,
         const float4 g = gw[it];
         bf16x4 o = {f2bf(v.x * inv * g.x), f2bf(v.y * inv * g.y), f2bf(v.z * inv * g.z), f2bf(v.w * inv * g.w)};
         *reinterpret_cast<bf16x4*>(yr + i) = o;
+        if (q8) {   // the quantiser sees the bf16 values the bf16 path would hand to the GEMV
+          keep[it] = make_float4(bf2f(o[0]), bf2f(o[1]), bf2f(o[2]), bf2f(o[3]));
+          am = fmaxf(fmaxf(am, fmaxf(fabsf(keep[it].x), fabsf(keep[it].y))), fmaxf(fabsf(keep[it].z), fabsf(keep[it].w)));
+        }
+      }
+    }
+    if (q8) {
+      // fused vr2_quant_rows_fp8 (gemv_w8.hip): e4m3 bytes in the two-k-step fragment order + the row's scale.  H % 64 == 0 (host)
+      am = block_max_256(am, scratch);
+      const float qi = am > 0.f ? 448.0f / am : 1.0f;
+      if (threadIdx.x == 0) qscale[m] = am > 0.f ? am / 448.0f : 1.0f;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int i = threadIdx.x * 4 + it * 1024;
+        if (i < H) {
+          int d = 0;
+          d = __builtin_amdgcn_cvt_pk_fp8_f32(keep[it].x * qi, keep[it].y * qi, d, false);
+          d = __builtin_amdgcn_cvt_pk_fp8_f32(keep[it].z * qi, keep[it].w * qi, d, true);
+          const int kk = i & 63;                                         // byte of the row: block, slot (kk % 32) / 8, half kk / 32
+          *reinterpret_cast<int*>(q8 + (long)m * ldq + (i & ~63) + ((kk & 31) >> 3) * 16 + (kk >> 5) * 8 + (kk & 7)) = d;
+        }
       }
     }
   } else {
@@ -350,12 +373,24 @@ extern "C" int vr2_add_rmsnorm(void* x_f32, int64_t ldx, const void* partial_f32
   if (H <= 4096)
     hipLaunchKernelGGL(add_rmsnorm_kernel<true>, dim3((unsigned)M), dim3(256), 0, STREAM, (float*)x_f32, (long)ldx,
                        (const float*)partial_f32, (long)split_stride, (long)ldp, nsplit, (const float*)bias_f32,
-                       (const float*)w_f32, (bf16*)y_bf16, (long)ldy, (int)H, eps);
+                       (const float*)w_f32, (bf16*)y_bf16, (long)ldy, (int)H, eps, (unsigned char*)nullptr, 0L, (float*)nullptr);
   else
     hipLaunchKernelGGL(add_rmsnorm_kernel<false>, dim3((unsigned)M), dim3(256), 0, STREAM, (float*)x_f32, (long)ldx,
                        (const float*)partial_f32, (long)split_stride, (long)ldp, nsplit, (const float*)bias_f32,
-                       (const float*)w_f32, (bf16*)y_bf16, (long)ldy, (int)H, eps);
+                       (const float*)w_f32, (bf16*)y_bf16, (long)ldy, (int)H, eps, (unsigned char*)nullptr, 0L, (float*)nullptr);
   return vr2_check_launch("vr2_add_rmsnorm");
+}
+
+extern "C" int vr2_add_rmsnorm_q8(void* x_f32, int64_t ldx, const void* partial_f32, int64_t split_stride, int64_t ldp, int nsplit,
+                                  const void* bias_f32, const void* w_f32, void* y_bf16, int64_t ldy, int64_t M, int64_t H,
+                                  float eps, void* q_fp8, int64_t ldq, void* qscale_f32, void* stream) {
+  VR2_REQUIRE(M >= 1 && H >= 64 && H % 64 == 0 && H <= 4096, "vr2_add_rmsnorm_q8: H=%ld must be a multiple of 64, <= 4096", (long)H);
+  VR2_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0 && split_stride % 4 == 0 && ldq % 16 == 0 && ldq >= H, "vr2_add_rmsnorm_q8: strides");
+  VR2_REQUIRE(y_bf16 != nullptr && w_f32 != nullptr && q_fp8 != nullptr && qscale_f32 != nullptr, "vr2_add_rmsnorm_q8: outputs missing");
+  hipLaunchKernelGGL(add_rmsnorm_kernel<true>, dim3((unsigned)M), dim3(256), 0, STREAM, (float*)x_f32, (long)ldx,
+                     (const float*)partial_f32, (long)split_stride, (long)ldp, nsplit, (const float*)bias_f32,
+                     (const float*)w_f32, (bf16*)y_bf16, (long)ldy, (int)H, eps, (unsigned char*)q_fp8, (long)ldq, (float*)qscale_f32);
+  return vr2_check_launch("vr2_add_rmsnorm_q8");
 }
 
 extern "C" int vr2_cast_rows_f32_bf16(const void* src_f32, int64_t lds_, const void* row_idx_i32, void* dst_bf16,

@@ -10,6 +10,8 @@
 // above 64 rows the activations' L2 -> LDS traffic dominates and the 128-k variant with a second k group wins
 // (128 rows: 6.8 vs 5.2 ms/token; 64 rows: both 3.8).
 #include "common.h"
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -450,7 +452,291 @@ void launch_w8(dim3 grid, hipStream_t st, const bf16* x, int ldx, int M, const u
 #undef VR2_W8_LAUNCH
 }
 
+// ---- fp8 activations x fp8 weights on the fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8), 16 < M <= 128 rows, K % 128 == 0 --------
+// BASELINE config 5 ("fp8 weights on CDNA4 fp8 MFMA").  Same one-workgroup-per-CU ring structure as gemv.hip's
+// gemv_ring_kernel (read its header comment first); what differs:
+//   * the weight tiles are the 16-row x 64-k fp8 tiles above: one 16-B load per lane = the A operands of TWO MFMA k-steps, so a
+//     128-k chunk is 4 loads per wave (two tiles x two 64-k steps), the same count as the bf16 kernel's 64-k chunk;
+//   * the activations arrive ALREADY quantised (vr2_quant_rows_fp8: e4m3 bytes, per-row scale, and inside every 64-k block
+//     the 16-byte slot s holds k = 8s..8s+7 followed by k = 32+8s..32+8s+7, the same two-k-step order as the weight tiles), so
+//     one ds_read_b128 per lane is the B operand of the same two k-steps; the LDS image of a chunk is [2 halves of 64 k][16*MB
+//     rows][64 B], slot XOR-swizzled by (-(row >> 2)) & 3 through the source address: conflict-free for ds_read_b128's four
+//     16-lane groups;
+//   * half the activation bytes per k (the L2 -> LDS traffic that is half of a CU's fetch budget at 128 rows) and half the
+//     weight bytes; the MFMA runs at the bf16 rate (twice as many per byte), scales (weight channel x activation row) multiply
+//     the fp32 accumulator in the epilogue.
+typedef __attribute__((ext_vector_type(4))) float wreg8;
+typedef __attribute__((ext_vector_type(2))) long l64x2;
+
+template <int MODE, int MB, int D>
+__global__ __launch_bounds__(512, 2) void gemv_ring8_kernel(const unsigned char* __restrict__ x8, int ldx8,
+                                                            const float* __restrict__ xscale, int M,
+                                                            const unsigned char* __restrict__ Wp, const float* __restrict__ wscale,
+                                                            int n_tiles, int N, int K, float* __restrict__ out_f32,
+                                                            long split_stride, int ldo, bf16* __restrict__ out_bf16) {
+  constexpr int NB = D + 1;
+  static_assert(MB >= 2 && (NB & (NB - 1)) == 0, "ring shape");
+  constexpr int CHUNKB = MB * 2048;                  // 16*MB rows x 128 k fp8
+  constexpr int PIECES = MB * 2;                     // 1-KiB pieces (16 rows x 64 B) of an x chunk: [half][16-row block]
+  constexpr int XP = PIECES >= 8 ? PIECES / 8 : 1;
+  extern __shared__ __attribute__((aligned(16))) char xring[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int dsteps = K >> 6, nchunks = K >> 7;
+  const int parts = gridDim.y, part = blockIdx.y;
+  const int pbase = nchunks / parts, prem = nchunks % parts;
+  const int pc0 = part * pbase + (part < prem ? part : prem);
+  const int n = pbase + (part < prem ? 1 : 0);
+  const int pairs = (n_tiles + 1) >> 1, groups = gridDim.x, g = blockIdx.x;
+  const int gbase = pairs / groups, grem = pairs % groups;
+  const int first = g * gbase + (g < grem ? g : grem), count = gbase + (g < grem ? 1 : 0);
+  const bool active = wave < count;
+  const int t0 = 2 * (first + (active ? wave : 0)), t1 = (t0 + 1 < n_tiles) ? t0 + 1 : t0;
+  const bool t1_valid = t0 + 1 < n_tiles;
+  const char* w0 = (const char*)(Wp + ((long)t0 * dsteps + 2 * pc0) * 1024);   // + 2 KiB per 128-k chunk
+  const char* w1 = (const char*)(Wp + ((long)t1 * dsteps + 2 * pc0) * 1024);
+  const unsigned wlane = lane * 16;
+  const char* xb = (const char*)x8 + (long)pc0 * 128;                         // + 128 B per chunk
+  unsigned xoff[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int p = (wave * XP + i) % PIECES, half = p / MB, blk = p % MB;
+    const int row = blk * 16 + (lane >> 2), sl = lane & 3;
+    const int m = row < M ? row : M - 1;
+    xoff[i] = (unsigned)(m * ldx8 + half * 64 + ((sl ^ ((-(row >> 2)) & 3)) << 4));
+  }
+  int staged = 0, loaded = 0;
+  auto stage = [&]() {
+    char* dst = xring + (staged & (NB - 1)) * CHUNKB;
+#pragma unroll
+    for (int i = 0; i < XP; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xoff[i]),
+                                       (__attribute__((address_space(3))) void*)(dst + ((wave * XP + i) % PIECES) * 1024), 16, 0, 0);
+    ++staged;
+    xb += staged < n ? 128 : 0;
+  };
+  const unsigned ring_u32 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)xring;
+  const unsigned frag = ring_u32 + r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4);
+
+  wreg8 acc0[MB], acc1[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) { acc0[mb] = wreg8{0.f, 0.f, 0.f, 0.f}; acc1[mb] = wreg8{0.f, 0.f, 0.f, 0.f}; }
+  l64x2 wa[NB][2], wb[NB][2];
+#define VR2_LOADW8(S_)                                                                                                  \
+  do {                                                                                                                  \
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wa[S_][0]) : "v"(wlane), "s"(w0) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wb[S_][0]) : "v"(wlane), "s"(w1) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=v"(wa[S_][1]) : "v"(wlane), "s"(w0) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=v"(wb[S_][1]) : "v"(wlane), "s"(w1) : "memory");   \
+    ++loaded;                                                                                                           \
+    { const int adv = loaded < n ? 2048 : 0; w0 += adv; w1 += adv; }                                                    \
+  } while (0)
+
+  auto kloop = [&](auto act) {
+    constexpr bool ACTIVE = decltype(act)::value;
+    constexpr int WL = ACTIVE ? 4 : 0;
+    constexpr int X_YOUNGER = D * WL + (D - 1) * XP;
+    constexpr int W_YOUNGER = D * WL + (D + 1) * XP;
+    static_assert(W_YOUNGER <= 63, "vmcnt is 6 bits");
+    auto& A0 = acc0; auto& A1 = acc1; auto& WA = wa; auto& WB = wb;
+    auto chunk = [&](int cc, auto jc, auto steady) {
+      constexpr int j = decltype(jc)::value;
+      constexpr bool STEADY = decltype(steady)::value;
+      auto& C0 = A0; auto& C1 = A1; auto& CA = WA; auto& CB = WB;
+      if constexpr (STEADY && ACTIVE) VR2_LOADW8((j + D) % NB);
+      if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(X_YOUNGER) : "memory");
+      else asm volatile("s_barrier" ::: "memory");
+      if constexpr (STEADY) stage();
+      if constexpr (ACTIVE) {
+        const unsigned a = frag + (unsigned)(cc & (NB - 1)) * CHUNKB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                // the two 64-k halves of the chunk
+          l64x2 b[MB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[mb]) : "v"(a), "n"((i * MB + mb) * 1024) : "memory");
+          const long a0lo = CA[j][i][0], a0hi = CA[j][i][1], a1lo = CB[j][i][0], a1hi = CB[j][i][1];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            if (i == 0 && mb == 0 && STEADY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_YOUNGER) : "memory");
+            const long blo = b[mb][0], bhi = b[mb][1];
+            asm volatile("s_waitcnt lgkmcnt(%8)\n\t"
+                         "v_mfma_f32_16x16x32_fp8_fp8 %0, %2, %6, %0\n\tv_mfma_f32_16x16x32_fp8_fp8 %1, %4, %6, %1\n\t"
+                         "v_mfma_f32_16x16x32_fp8_fp8 %0, %3, %7, %0\n\tv_mfma_f32_16x16x32_fp8_fp8 %1, %5, %7, %1"
+                         : "+v"(C0[mb]), "+v"(C1[mb])
+                         : "v"(a0lo), "v"(a0hi), "v"(a1lo), "v"(a1hi), "v"(blo), "v"(bhi), "n"(MB - 1 - mb));
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      if constexpr (ACTIVE) VR2_LOADW8(j);
+      stage();
+    }
+    int cb = 0;
+    for (; cb < n - D; cb += NB) {
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        (chunk(cb + J, std::integral_constant<int, J>{}, std::true_type{}), ...);
+      }(std::make_integer_sequence<int, NB>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+      ((cb + J < n ? (chunk(cb + J, std::integral_constant<int, J>{}, std::false_type{}),
+                      (void)({ asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); 0; }))
+                   : (void)0), ...);
+    }(std::make_integer_sequence<int, D>{});
+  };
+  if (active) kloop(std::true_type{});
+  else { kloop(std::false_type{}); return; }
+#undef VR2_LOADW8
+  // D layout (16x16): lane holds col = m = lane&15, rows n = 4*(lane>>4)+i of the tile; scale = weight channel x activation row
+  const float4 sa = *reinterpret_cast<const float4*>(wscale + t0 * 16 + 4 * q);
+  const float4 sb = *reinterpret_cast<const float4*>(wscale + t1 * 16 + 4 * q);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const long row = mb * 16 + r;
+    if (row >= M) continue;
+    const float xs = xscale[row];
+    const float g0 = acc0[mb][0] * sa.x * xs, g1 = acc0[mb][1] * sa.y * xs, g2 = acc0[mb][2] * sa.z * xs, g3 = acc0[mb][3] * sa.w * xs;
+    const float u0 = acc1[mb][0] * sb.x * xs, u1 = acc1[mb][1] * sb.y * xs, u2 = acc1[mb][2] * sb.z * xs, u3 = acc1[mb][3] * sb.w * xs;
+    if (MODE == 0) {
+      float* o = out_f32 + (long)blockIdx.y * split_stride + row * ldo;
+      const int na = t0 * 16 + 4 * q, nb = t1 * 16 + 4 * q;
+      if (na < N) *reinterpret_cast<float4*>(o + na) = make_float4(g0, g1, g2, g3);
+      if (t1_valid && nb < N) *reinterpret_cast<float4*>(o + nb) = make_float4(u0, u1, u2, u3);
+    } else {
+      const int nn = (t0 >> 1) * 16 + 4 * q;
+      if (t1_valid && nn < N) {
+        bf16x4 o = {f2bf(g0 / (1.0f + expf(-g0)) * u0), f2bf(g1 / (1.0f + expf(-g1)) * u1), f2bf(g2 / (1.0f + expf(-g2)) * u2),
+                    f2bf(g3 / (1.0f + expf(-g3)) * u3)};
+        *reinterpret_cast<bf16x4*>(out_bf16 + row * ldo + nn) = o;
+      }
+    }
+  }
+}
+
+// x bf16 [M][K] -> e4m3 bytes [M][Kpad] (Kpad = K rounded up to 64, zero padded) + scale[m] = amax / 448 (1 for an all-zero row):
+// x ~= float(q) * scale.  Inside every 64-k block the 16-byte slot s holds k = 8s..8s+7 then k = 32+8s..32+8s+7 (see above).
+template <int NS>   // NS = 16-byte output slots per thread kept in registers (K <= 256 * 16 * NS); the row is read ONCE
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restrict__ x, long ldx, int K, unsigned char* __restrict__ q8,
+                                                             long ldq, float* __restrict__ scale) {
+  __shared__ float scratch[4];
+  const int row = blockIdx.x;
+  const bf16* xr = x + (long)row * ldx;
+  const int slots = ((K + 63) >> 6) * 4;            // 16-byte output slots of the row
+  bf16x8 v[NS][2];
+  float am = 0.f;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int s = threadIdx.x + j * 256;
+    const int k0 = (s >> 2) * 64 + (s & 3) * 8;     // slot s: k0 .. k0+7 and k0+32 .. k0+39
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + 32 * h;
+      if (s < slots && k + 8 <= K) v[j][h] = *reinterpret_cast<const bf16x8*>(xr + k);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[j][h][i] = (s < slots && k + i < K) ? xr[k + i] : f2bf(0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(bf2f(v[j][h][i])));
+    }
+  }
+  am = block_max_256(am, scratch);
+  const float inv = am > 0.f ? 448.0f / am : 1.0f;
+  if (threadIdx.x == 0) scale[row] = am > 0.f ? am / 448.0f : 1.0f;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int s = threadIdx.x + j * 256;
+    if (s >= slots) continue;
+    unsigned o[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int lo = 0, hi = 0;                            // v_cvt_pk_fp8_f32: round to nearest even, = torch's float8_e4m3fn cast
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[j][h][0]) * inv, bf2f(v[j][h][1]) * inv, lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[j][h][2]) * inv, bf2f(v[j][h][3]) * inv, lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[j][h][4]) * inv, bf2f(v[j][h][5]) * inv, hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v[j][h][6]) * inv, bf2f(v[j][h][7]) * inv, hi, true);
+      o[2 * h] = (unsigned)lo; o[2 * h + 1] = (unsigned)hi;
+    }
+    *reinterpret_cast<uint4*>(q8 + (long)row * ldq + (long)s * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int ring8_groups(int pairs, int parts) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    ncu = prop.multiProcessorCount;
+  }
+  const long units = (long)pairs * parts;
+  const int rounds = (int)((units + 8L * ncu - 1) / (8L * ncu));
+  int groups = (ncu * rounds) / parts;
+  if (groups < 1) groups = 1;
+  if (groups > pairs) groups = pairs;
+  while ((pairs + groups - 1) / groups > 8) ++groups;
+  return groups;
+}
+
+template <int MODE>
+int launch_a8w8(const void* x8, int64_t ldx8, const void* xscale, int64_t M, const void* W8, const void* wscale, int n_tiles, int N,
+                int64_t K, float* of, long split_stride, int ldo, bf16* ob, int nsplit, void* stream) {
+  const int groups = ring8_groups((n_tiles + 1) / 2, nsplit);
+  if (groups <= 0) { vr2_set_error("vr2_gemv_a8w8: no device"); return -2; }
+  const dim3 gr((unsigned)groups, (unsigned)nsplit);
+#define VR2_RING8(MB_)                                                                                                          \
+  do {                                                                                                                          \
+    static bool attr = false;                                                                                                   \
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_ring8_kernel<MODE, MB_, 1>),                      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MB_ * 2048); attr = true; }          \
+    hipLaunchKernelGGL((gemv_ring8_kernel<MODE, MB_, 1>), gr, dim3(512), 2 * MB_ * 2048, (hipStream_t)stream,                   \
+                       (const unsigned char*)x8, (int)ldx8, (const float*)xscale, (int)M, (const unsigned char*)W8,             \
+                       (const float*)wscale, n_tiles, N, (int)K, of, split_stride, ldo, ob);                                    \
+  } while (0)
+  if (M <= 32) VR2_RING8(2); else if (M <= 64) VR2_RING8(4); else VR2_RING8(8);
+#undef VR2_RING8
+  return 0;
+}
+
 }  // namespace
+
+extern "C" int vr2_quant_rows_fp8(const void* x_bf16, int64_t ldx, int64_t M, int64_t K, void* q_fp8, int64_t ldq, void* scale_f32,
+                                  void* stream) {
+  VR2_REQUIRE(M >= 1 && K >= 1 && ldx % 8 == 0 && ldq % 16 == 0 && ldq >= (K + 63) / 64 * 64, "vr2_quant_rows_fp8: bad shape");
+  const long slots = (K + 63) / 64 * 4;
+  VR2_REQUIRE(slots <= 256 * 8, "vr2_quant_rows_fp8: K=%ld above 32768", (long)K);
+#define VR2_QUANT(NS_)                                                                                                           \
+  hipLaunchKernelGGL(quant_rows_fp8_kernel<NS_>, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, (const bf16*)x_bf16, (long)ldx, \
+                     (int)K, (unsigned char*)q_fp8, (long)ldq, (float*)scale_f32)
+  if (slots <= 256) VR2_QUANT(1); else if (slots <= 512) VR2_QUANT(2); else if (slots <= 1280) VR2_QUANT(5); else VR2_QUANT(8);
+#undef VR2_QUANT
+  return vr2_check_launch("vr2_quant_rows_fp8");
+}
+
+extern "C" int vr2_gemv_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64_t M, const void* Wpacked_fp8,
+                             const void* wscale_f32, int64_t N, int64_t K, void* out_f32, int64_t split_stride, int64_t ldo,
+                             int nsplit, void* stream) {
+  VR2_REQUIRE(M > 16 && M <= 128, "vr2_gemv_a8w8: M=%ld must be in (16,128]", (long)M);
+  VR2_REQUIRE(K % 128 == 0 && N % 4 == 0 && ldx8 % 16 == 0 && ldx8 >= K && ldo % 4 == 0, "vr2_gemv_a8w8: K=%ld %% 128, N=%ld %% 4, strides", (long)K, (long)N);
+  VR2_REQUIRE(nsplit >= 1 && (K / 128) >= (int64_t)nsplit, "vr2_gemv_a8w8: nsplit=%d too large for K=%ld", nsplit, (long)K);
+  const int n_tiles = (int)((N + 15) / 16);
+  if (launch_a8w8<0>(x_fp8, ldx8, xscale_f32, M, Wpacked_fp8, wscale_f32, n_tiles, (int)N, K, (float*)out_f32, (long)split_stride,
+                     (int)ldo, (bf16*)nullptr, nsplit, stream)) return -2;
+  return vr2_check_launch("vr2_gemv_a8w8");
+}
+
+extern "C" int vr2_gemv_gateup_silu_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64_t M, const void* Wpacked_fp8,
+                                         const void* wscale_f32, int64_t I, int64_t K, void* act_bf16, int64_t ldo, void* stream) {
+  VR2_REQUIRE(M > 16 && M <= 128, "vr2_gemv_gateup_silu_a8w8: M=%ld must be in (16,128]", (long)M);
+  VR2_REQUIRE(K % 128 == 0 && I % 16 == 0 && ldx8 % 16 == 0 && ldx8 >= K && ldo % 4 == 0, "vr2_gemv_gateup_silu_a8w8: bad shape");
+  const int it = (int)(I / 16);
+  if (launch_a8w8<1>(x_fp8, ldx8, xscale_f32, M, Wpacked_fp8, wscale_f32, 2 * it, (int)I, K, (float*)nullptr, 0L, (int)ldo,
+                     (bf16*)act_bf16, 1, stream)) return -2;
+  return vr2_check_launch("vr2_gemv_gateup_silu_a8w8");
+}
 
 extern "C" int vr2_gemv_w8(const void* x, int64_t ldx, int64_t M, const void* Wpacked_fp8, const void* scale_f32, int64_t N,
                            int64_t K, void* out_f32, int64_t split_stride, int64_t ldo, int nsplit, void* stream) {

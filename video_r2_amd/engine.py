@@ -90,6 +90,7 @@ class Engine:
         self._graphs = {}
         self.decode_fp8 = False      # decode GEMVs stream per-channel e4m3 weight copies (weights.add_fp8_decode_copies; config 5)
         self.decode_fp8_max_rows = 128
+        self.decode_fp8_act = True   # ... and, above 16 rows, fp8 ACTIVATIONS on the fp8 MFMA (vr2_quant_rows_fp8 + vr2_gemv_a8w8)
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -134,9 +135,29 @@ class Engine:
             raise lib.Vr2Error(f"decode_fp8 is on but {wname} has no fp8 copy: call weights.add_fp8_decode_copies(params) first")
         return f8[wname]
 
-    def _gemv(self, x, P: Params, wname, G, out, nsplit):
+    def _quant(self, x, G, K):
+        """bf16 activation rows -> (e4m3 bytes in the fragment order of vr2_gemv_a8w8, per-row scales); one shared workspace"""
+        q8, xs = self._qbuf(G)
+        lib.call("vr2_quant_rows_fp8", x, x.stride(0), G, K, q8, q8.stride(0), xs, self.s)
+        return q8, xs
+
+    def _a8w8(self, P: Params, wname, G):
+        """fp8 activations x fp8 weights on the fp8 MFMA: above 16 rows, K a multiple of 128, when the mode is on"""
+        return self.decode_fp8 and self.decode_fp8_act and 16 < G <= self.decode_fp8_max_rows and P.shape[wname][1] % 128 == 0
+
+    def _qbuf(self, G):
+        t = self.cfg.text
+        width = 128 * ((max(t.intermediate_size, t.hidden_size, t.num_attention_heads * t.head_dim) + 127) // 128)
+        return self.buf("d.q8", (G, width), torch.uint8), self.buf("d.q8s", (G,), torch.float32)
+
+    def _gemv(self, x, P: Params, wname, G, out, nsplit, prequant=None):
         n, kp = P.shape[wname]
         f8 = self._f8(P, wname, G)
+        if f8 is not None and self._a8w8(P, wname, G) and kp // 128 >= nsplit:
+            q8, xs = prequant if prequant is not None else self._quant(x, G, kp)
+            lib.call("vr2_gemv_a8w8", q8, q8.stride(0), xs, G, f8[0], f8[1], n, kp, out, out.stride(0) if nsplit > 1 else 0,
+                     out.stride(-2), nsplit, self.s)
+            return
         if f8 is not None:
             lib.call("vr2_gemv_w8", x, x.stride(0), G, f8[0], f8[1], n, kp, out, out.stride(0) if nsplit > 1 else 0,
                      out.stride(-2), nsplit, self.s)
@@ -144,7 +165,12 @@ class Engine:
         lib.call("vr2_gemv_bf16", x, x.stride(0), G, P[wname], n, kp, out, out.stride(0) if nsplit > 1 else 0,
                  out.stride(-2), nsplit, self.s)
 
-    def _norm(self, x, w, y, M, H, eps, partial=None, nsplit=0, bias=None):
+    def _norm(self, x, w, y, M, H, eps, partial=None, nsplit=0, bias=None, q8=None):
+        """q8 = (bytes, scales): also emit the row's e4m3 quantisation for the fp8-activation GEMV that follows (decode, config 5)"""
+        if q8 is not None:
+            ps = (partial, partial.stride(0), partial.stride(1), nsplit, bias) if partial is not None else (None, 0, 0, 0, None)
+            lib.call("vr2_add_rmsnorm_q8", x, x.stride(0), *ps, w, y, y.stride(0), M, H, eps, q8[0], q8[0].stride(0), q8[1], self.s)
+            return
         if partial is None:
             lib.call("vr2_add_rmsnorm", x, x.stride(0), None, 0, 0, 0, None, w, y, 0 if y is None else y.stride(0), M, H, eps, self.s)
         else:
@@ -521,12 +547,14 @@ class Engine:
         ns_q, ns_o, ns_d = p_qkv.shape[0], p_o.shape[0], p_d.shape[0]
         lib.call("vr2_embed_rows", bufs["next_ids"], W["embed"], W["embed"].stride(0), x, x.stride(0), G, H, self.s)
         scale = hd ** -0.5
+        # config 5 above 16 rows: the norms also emit the e4m3 quantisation of their output (fused), att and act get their own pass
+        fq = self._qbuf(G) if (self._a8w8(W, "l0.qkv_w", G) and H % 64 == 0 and H <= 4096 and H // 128 >= max(ns_q, 1)) else None
         for l in range(t.num_hidden_layers):
             if l == 0:
-                self._norm(x, W["l0.ln1"], xn, G, H, t.rms_norm_eps)
+                self._norm(x, W["l0.ln1"], xn, G, H, t.rms_norm_eps, q8=fq)
             else:
-                self._norm(x, W[f"l{l}.ln1"], xn, G, H, t.rms_norm_eps, partial=p_d, nsplit=ns_d)
-            self._gemv(xn, W, f"l{l}.qkv_w", G, p_qkv, ns_q)
+                self._norm(x, W[f"l{l}.ln1"], xn, G, H, t.rms_norm_eps, partial=p_d, nsplit=ns_d, q8=fq)
+            self._gemv(xn, W, f"l{l}.qkv_w", G, p_qkv, ns_q, prequant=fq)
             sk, sv = bufs["suffix_k"][l], bufs["suffix_v"][l]
             lib.call("vr2_rope_append_decode", p_qkv, p_qkv.stride(0), p_qkv.stride(1), ns_q, W[f"l{l}.qkv_b"], bufs["pos"],
                      bufs["step"], self.inv_freq, G, nq, nkv, hd, q, q.stride(0), sk, sv, sk.stride(0), C, self.s)
@@ -534,15 +562,18 @@ class Engine:
                      bufs["spg"], bufs["pstride"], C, bufs["step"], bufs["schunk"], bufs["pchunk"], bufs["npc"], bufs["nsc"], G, nq, t.group, hd, scale,
                      bufs["part_o"], bufs["part_ml"], att, att.stride(0), self.s)
             self._gemv(att, W, f"l{l}.o_w", G, p_o, ns_o)
-            self._norm(x, W[f"l{l}.ln2"], xn, G, H, t.rms_norm_eps, partial=p_o, nsplit=ns_o)
+            self._norm(x, W[f"l{l}.ln2"], xn, G, H, t.rms_norm_eps, partial=p_o, nsplit=ns_o, q8=fq)
             f8 = self._f8(W, f"l{l}.gu_w", G)
-            if f8 is not None:
+            if f8 is not None and self._a8w8(W, f"l{l}.gu_w", G):
+                q8, xs = fq if fq is not None else self._quant(xn, G, H)
+                lib.call("vr2_gemv_gateup_silu_a8w8", q8, q8.stride(0), xs, G, f8[0], f8[1], I, H, act, act.stride(0), self.s)
+            elif f8 is not None:
                 lib.call("vr2_gemv_gateup_silu_w8", xn, xn.stride(0), G, f8[0], f8[1], I, H, act, act.stride(0), self.s)
             else:
                 lib.call("vr2_gemv_gateup_silu_bf16", xn, xn.stride(0), G, W[f"l{l}.gu_w"], I, H, act, act.stride(0), self.s)
             self._gemv(act, W, f"l{l}.down_w", G, p_d, ns_d)
-        self._norm(x, W["norm"], xn, G, H, t.rms_norm_eps, partial=p_d, nsplit=ns_d)
-        self._gemv(xn, W, "lm_head", G, logits, 1)
+        self._norm(x, W["norm"], xn, G, H, t.rms_norm_eps, partial=p_d, nsplit=ns_d, q8=fq)
+        self._gemv(xn, W, "lm_head", G, logits, 1, prequant=fq)
         # token index step+1 is sampled from the logits of token `step`
         tok1 = bufs["tokens"][:, 1:]
         lib.call("vr2_sample_topk", logits, logits.stride(0), G, V, temperature, top_k, 0, seed_dev, bufs["step"],
@@ -659,7 +690,8 @@ class Engine:
             seed_dev.fill_(int(seed) & (2**63 - 1))
 
         step_args = (W, None, NG, C, b, temperature, top_k, seed_dev, eos, cfg.pad_token_id)
-        key = (id(W), NG, P, C, cap_s, float(temperature), int(top_k), eos, k0.data_ptr(), pstride, self._ws_epoch, bool(self.decode_fp8))
+        key = (id(W), NG, P, C, cap_s, float(temperature), int(top_k), eos, k0.data_ptr(), pstride, self._ws_epoch, bool(self.decode_fp8),
+               bool(self.decode_fp8_act))
         graph = None
         if getattr(self, "_graph_epoch", -1) != self._ws_epoch:       # a workspace moved: every captured graph is stale
             for ex_ in self._graphs.values():

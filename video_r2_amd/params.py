@@ -95,7 +95,8 @@ class GRPOArguments:
     loss_norm_unit: str = "per_device_batch"   # token-mean losses (bnpo, mapo_bnpo) + kl / clip metrics are normalised over blocks of
                                       # per_device_train_batch_size completions and averaged, as the reference's ranks do;
                                       # "rank": over all completions a rank holds (round-1 behaviour of this engine)
-    decode_weights: str = "bf16"     # "fp8": rollout decode streams per-channel e4m3 weight copies (up to 64 sequences per pass)
+    decode_weights: str = "bf16"     # "fp8": rollout decode on per-channel e4m3 weight copies and (above 16 rows) per-row e4m3 activations
+                                      # on the fp8 MFMA (BASELINE config 5); "fp8w": weight-only fp8
     async_rewards: bool = True        # reward functions run on a background thread behind the reference-model scoring
     ignored: dict = field(default_factory=dict)
 

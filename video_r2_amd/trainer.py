@@ -113,9 +113,10 @@ class QwenGRPOTrainer:
         self.sampler = RepeatSampler(train_dataset, mini_repeat_count=self.num_generations, batch_size=self.groups_per_step,
                                      repeat_count=args.num_iterations, shuffle=args.shuffle_dataset, seed=args.seed)
         self._buffered = None
-        if getattr(args, "decode_weights", "bf16") == "fp8":
+        if getattr(args, "decode_weights", "bf16") in ("fp8", "fp8w"):
             vw.add_fp8_decode_copies(model.text)
             model.engine.decode_fp8 = True
+            model.engine.decode_fp8_act = args.decode_weights == "fp8"     # fp8w: weight-only (bf16 activations)
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
         self.update = not getattr(args, "freeze_llm", False)
         self.updater = UpdateEngine(model.engine, model.text) if self.update else None

@@ -126,6 +126,73 @@ def test_reward_module_seam_and_sentence_model_passthrough(tmp_path, monkeypatch
     assert rewards.resolve_reward_module(None) == "video_r2_amd.rewards" and rewards.resolve_reward_module("x.y") == "x.y"
 
 
+def test_reward_rows_are_scored_concurrently_and_in_order():
+    """--reward_workers: a slow (judge-like) row-wise reward over 16 rows on 4 threads takes about a quarter of the serial time and
+    returns the rows in order; dataset columns are sliced with the rows, scalars are passed through"""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    from video_r2_amd.trainer import call_reward_funcs
+
+    def slow_reward(completions, assistant, buffer_seconds, **kwargs):
+        assert len(assistant) == len(completions) == len(kwargs["prompts"]) and buffer_seconds == 2
+        out = []
+        for c, a in zip(completions, assistant):
+            time.sleep(0.05)
+            out.append(float(c[0]["content"]) + a)
+        return out
+    a = params.parse_args([])
+    exs = [{"prompt": [f"p{i}"], "assistant": 100.0 * i} for i in range(4)]
+    texts = [[str(4 * i + g) for g in range(4)] for i in range(4)]
+    t0 = time.time()
+    serial = call_reward_funcs([slow_reward], ["slow_reward"], exs, texts, a)
+    t_serial = time.time() - t0
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        t0 = time.time()
+        par = call_reward_funcs([slow_reward], ["slow_reward"], exs, texts, a, pool=pool, workers=4)
+        t_par = time.time() - t0
+    assert torch.equal(serial, par) and serial[:, 0].tolist() == [100.0 * (r // 4) + r for r in range(16)]
+    assert t_par < 0.5 * t_serial, (t_par, t_serial)
+
+
+def test_judge_client_speaks_the_openai_chat_contract(monkeypatch):
+    """rewards.chat() against a local stand-in for the vLLM judge (train/serve_llm: OpenAI /v1/chat/completions): request
+    shape (model from SERVED_MODEL, system + user message, stream false, bearer key), response parsing, and the 10 s timeout
+    turning into an exception (which reward functions map to 0.0)"""
+    import http.server
+    import json
+    import threading
+    seen = {}
+
+    class H(http.server.BaseHTTPRequestHandler):
+        def do_POST(self):
+            body = json.loads(self.rfile.read(int(self.headers["Content-Length"])))
+            seen.update(path=self.path, auth=self.headers.get("Authorization"), body=body)
+            if body["messages"][1]["content"] == "hang":
+                import time
+                time.sleep(1.0)
+            out = json.dumps({"choices": [{"message": {"role": "assistant", "content": " TRUE\nbecause "}}]}).encode()
+            self.send_response(200); self.send_header("Content-Type", "application/json"); self.send_header("Content-Length", str(len(out)))
+            self.end_headers(); self.wfile.write(out)
+
+        def log_message(self, *a):
+            pass
+    srv = http.server.ThreadingHTTPServer(("127.0.0.1", 0), H)
+    th = threading.Thread(target=srv.serve_forever, daemon=True)
+    th.start()
+    try:
+        monkeypatch.setenv("OPENAI_API_BASE", f"http://127.0.0.1:{srv.server_address[1]}/v1")
+        monkeypatch.setenv("SERVED_MODEL", "judge-model")
+        monkeypatch.delenv("OPENAI_API_KEY", raising=False)
+        assert rewards.chat("you are a judge", "is it consistent?") == "TRUE\nbecause"
+        assert seen["path"] == "/v1/chat/completions" and seen["auth"] == "Bearer EMPTY"
+        assert seen["body"] == {"model": "judge-model", "stream": False,
+                                "messages": [{"role": "system", "content": "you are a judge"}, {"role": "user", "content": "is it consistent?"}]}
+        with pytest.raises(Exception):
+            rewards.chat("s", "hang", timeout=0.2)
+    finally:
+        srv.shutdown()
+
+
 @pytest.mark.parametrize("loss_type", ["bnpo", "mapo", "mapo_bnpo", "grpo"])
 def test_group_advantages_match_oracle(loss_type):
     rng = np.random.default_rng(3)

@@ -111,6 +111,41 @@ def test_rows_with_equal_ids_but_different_videos_are_not_merged():
                    generation_config=GenerationConfig(max_new_tokens=4, top_p=0.9))
 
 
+def test_generate_with_hf_keyword_arguments_as_the_eval_harness_calls_it():
+    """lmms-eval's model wrapper calls model.generate(**inputs, eos_token_id=, pad_token_id=, do_sample=False, temperature=None,
+    top_p=None, num_beams=1, max_new_tokens=, use_cache=) (eval/lmms-eval/lmms_eval/models/qwen2_5_vl.py:326-336): greedy decode,
+    deterministic, equal to the argmax of the oracle's teacher-forced logits; HF-only options are refused, not ignored."""
+    m, w, ocfg = _model(2, 43)
+    cfg = m.cfg
+    g = torch.Generator().manual_seed(4)
+    frames = torch.randint(0, 256, (2, 3, 56, 84), generator=g, dtype=torch.uint8).numpy()
+    px, grid = pixels_from_frames(frames, cfg.vision)
+    tv = grid[0] * grid[1] * grid[2] // 4
+    p = [21, cfg.vision_start_token_id] + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 30, 31, 32]
+    ids = torch.tensor([p])
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values_videos=torch.from_numpy(px).cuda(),
+              video_grid_thw=torch.tensor([grid]), second_per_grid_ts=[1.0])
+    C = 6
+    out = m.generate(**kw, eos_token_id=-1, pad_token_id=cfg.pad_token_id, do_sample=False, temperature=None, top_p=None, num_beams=1,
+                     max_new_tokens=C, use_cache=True)
+    out2 = m.generate(**kw, eos_token_id=-1, pad_token_id=cfg.pad_token_id, do_sample=False, temperature=None, top_p=None, num_beams=1,
+                      max_new_tokens=C, use_cache=True)
+    assert out.shape == (1, ids.shape[1] + C) and torch.equal(out, out2)
+    full = out.cpu()
+    logits = om.forward_logits(w, ocfg, full, np.ones_like(full.numpy()), torch.from_numpy(px), np.asarray([grid]), [1.0])
+    S = ids.shape[1]
+    top2 = logits[0, S - 1:S + C - 1].topk(2, -1)
+    for j in range(C):                                           # the chosen token is the oracle's argmax (unless the top two are a near tie)
+        tok = int(full[0, S + j])
+        assert tok == int(top2.indices[j, 0]) or float(top2.values[j, 0] - top2.values[j, 1]) < 2e-2, j
+    with pytest.raises(ValueError, match="beam"):
+        m.generate(**kw, num_beams=4, max_new_tokens=2)
+    with pytest.raises(ValueError, match="top-k only"):
+        m.generate(**kw, do_sample=True, temperature=0.7, top_p=0.9, max_new_tokens=2)
+    with pytest.raises(NotImplementedError):
+        m.generate(**kw, pixel_values=torch.zeros(4, 1176), max_new_tokens=2)
+
+
 def test_save_pretrained_roundtrip(tmp_path):
     from video_r2_amd.model import VideoR2Model
     m, w, ocfg = _model(7, 23)

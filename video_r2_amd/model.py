@@ -145,8 +145,30 @@ class VideoR2Model:
 
     @torch.no_grad()
     def generate(self, input_ids, attention_mask=None, pixel_values_videos=None, video_grid_thw=None,
-                 second_per_grid_ts=None, generation_config: GenerationConfig | None = None, **_ignored):
-        gc = generation_config or GenerationConfig()
+                 second_per_grid_ts=None, generation_config: GenerationConfig | None = None, **hf_kwargs):
+        """Also takes HF ``generate`` keyword arguments in place of a generation_config -- max_new_tokens, do_sample,
+        temperature, top_k, top_p, num_beams, eos_token_id, pad_token_id, use_cache -- which is how the evaluation harness
+        calls its model (/root/reference/eval/lmms-eval/lmms_eval/models/qwen2_5_vl.py:326-336): greedy when do_sample is
+        false, beams and nucleus sampling refused (not silently ignored), image inputs refused (video path only)."""
+        if hf_kwargs.get("pixel_values") is not None or hf_kwargs.get("image_grid_thw") is not None:
+            raise NotImplementedError("VideoR2Model.generate: image inputs are not supported (video rollout path only)")
+        if generation_config is None:
+            gc = GenerationConfig()
+            for k in ("max_new_tokens", "do_sample", "top_k", "eos_token_id", "pad_token_id"):
+                if hf_kwargs.get(k) is not None:
+                    setattr(gc, k, hf_kwargs[k])
+            if hf_kwargs.get("temperature") is not None:
+                gc.temperature = float(hf_kwargs["temperature"])
+            if hf_kwargs.get("top_p") is not None:
+                gc.top_p = float(hf_kwargs["top_p"])
+            if "do_sample" in hf_kwargs and not hf_kwargs["do_sample"]:
+                gc.top_p = 1.0                                   # HF ignores the warpers without sampling
+        else:
+            gc = generation_config
+        if (hf_kwargs.get("num_beams") or 1) != 1:
+            raise ValueError(f"num_beams={hf_kwargs['num_beams']}: the engine samples or decodes greedily, it has no beam search")
+        if isinstance(gc.eos_token_id, (list, tuple)):
+            gc.eos_token_id = gc.eos_token_id[0]                 # one stop id (the tokenizer's, as the trainer and the harness pass it)
         cfg = self.cfg
         ids = input_ids.cpu().numpy()
         mask = np.ones_like(ids) if attention_mask is None else attention_mask.cpu().numpy()

@@ -98,6 +98,7 @@ class GRPOArguments:
     decode_weights: str = "bf16"     # "fp8": rollout decode on per-channel e4m3 weight copies and (above 16 rows) per-row e4m3 activations
                                       # on the fp8 MFMA (BASELINE config 5); "fp8w": weight-only fp8
     async_rewards: bool = True        # reward functions run on a background thread behind the reference-model scoring
+    reward_workers: int = 4           # each reward function scores this many slices of the step's completions concurrently (1 = one call)
     ignored: dict = field(default_factory=dict)
 
 

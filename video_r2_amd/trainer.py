@@ -24,10 +24,13 @@ from .train import Trainer as UpdateEngine
 from .train import cosine_lr
 
 
-def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_example, args, sentence_model=None):
+def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_example, args, sentence_model=None, pool=None, workers=1):
     """The reward loop of the reference (grpo_trainer.py:846-892) for whole prompt groups: one row per completion, in group
     order.  Every dataset column except "prompt" / "completion" is repeated per completion and forwarded, plus the three knobs
-    of :871-875; the TAR family additionally gets sentence_model= (:878-886).  None -> NaN.  -> fp32 [rows, n_funcs] (CPU)."""
+    of :871-875; the TAR family additionally gets sentence_model= (:878-886).  None -> NaN.  -> fp32 [rows, n_funcs] (CPU).
+    workers > 1 (--reward_workers): every function is called on `workers` contiguous slices of the rows from a thread pool -- the
+    shipped functions score row by row, and the judge-backed ones spend their time in HTTP round trips (two per completion,
+    up to 10 s each: temporal_grounding_reward.py:311-317, reward_funcs.py:103-137), which then overlap."""
     from .rewards import SENTENCE_MODEL_REWARDS
     prompts, completions, cols = [], [], defaultdict(list)
     for ex, texts in zip(examples, texts_per_example):
@@ -41,9 +44,20 @@ def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_examp
     kw.update(length_reinforcement_buffer=args.length_reinforcement_buffer, buffer_seconds=args.buffer_seconds,
               similarity_threshold=args.similarity_threshold)
     out = torch.zeros(len(prompts), len(reward_funcs))
+    n = len(prompts)
+    cuts = [n * j // workers for j in range(workers + 1)] if (pool is not None and workers > 1 and n >= 2 * workers) else [0, n]
+    per_row = {k for k, v in kw.items() if isinstance(v, list) and len(v) == n}
     for i, (fn, name) in enumerate(zip(reward_funcs, reward_func_names)):
         extra = {"sentence_model": sentence_model} if name in SENTENCE_MODEL_REWARDS else {}
-        vals = fn(prompts=prompts, completions=completions, **extra, **kw)
+
+        def part(a, b, fn=fn, extra=extra):
+            sl = {k: (v[a:b] if k in per_row else v) for k, v in kw.items()}
+            return fn(prompts=prompts[a:b], completions=completions[a:b], **extra, **sl)
+        if len(cuts) == 2:
+            vals = part(0, n)
+        else:
+            futs = [pool.submit(part, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+            vals = [v for f in futs for v in f.result()]
         out[:, i] = torch.tensor([float("nan") if v is None else float(v) for v in vals], dtype=torch.float32)
     if len(prompts) and torch.isnan(out).all(dim=1).any():
         row = int(torch.isnan(out).all(dim=1).nonzero()[0, 0])
@@ -118,6 +132,7 @@ class QwenGRPOTrainer:
             model.engine.decode_fp8 = True
             model.engine.decode_fp8_act = args.decode_weights == "fp8"     # fp8w: weight-only (bf16 activations)
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
+        self._row_pool = None                        # --reward_workers threads that split a reward function's rows
         self.update = not getattr(args, "freeze_llm", False)
         self.updater = UpdateEngine(model.engine, model.text) if self.update else None
         self.steps_per_epoch = len(train_dataset) // self.groups_per_step
@@ -208,7 +223,12 @@ class QwenGRPOTrainer:
         texts = [ro["decode"](ro["completion_ids"]) if ro["decode"] else [""] * G for ro in rollouts]
         for ro, t in zip(rollouts, texts):
             ro["texts"] = t
-        return call_reward_funcs(self.reward_funcs, self.reward_func_names, examples, texts, self.args, self.sentence_model)
+        workers = max(1, int(getattr(self.args, "reward_workers", 1)))
+        if workers > 1 and self._row_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._row_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vr2-reward-rows")
+        return call_reward_funcs(self.reward_funcs, self.reward_func_names, examples, texts, self.args, self.sentence_model,
+                                 pool=self._row_pool, workers=workers)
 
     # ------------------------------------------------------------------ one optimisation step (forward half)
     def step(self, step_examples, processed=None):

@@ -413,3 +413,42 @@ def test_trainer_step_with_fp8_decode_weights():
     assert q_after.data_ptr() == ptr and (not torch.equal(q_after, q_before) or not torch.equal(s_after, s_before))
     out2 = tr.step([data[2], data[3]])                              # second rollout replays the graphs on the refreshed copies
     assert np.isfinite(out2["loss"])
+
+
+def _rccl_single_rank_worker(port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from video_r2_amd import lib
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", world_size=1, rank=0, device_id=torch.device("cuda:0"))
+    lib.load()                                                   # libvr2.so and RCCL share one HIP runtime in this process
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda:0")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        y = torch.zeros(4, 512, dtype=torch.bfloat16, device="cuda:0")
+        lib.call("vr2_cast_rows_f32_bf16", x.view(2048, 512), 512, None, y, 512, 4, 512, 512, st.cuda_stream)
+        wk = dist.all_reduce(x, async_op=True)                   # ordered after the kernel above, runs on RCCL's stream
+        wk.wait()
+        got = [torch.zeros(1, dtype=torch.float64, device="cuda:0")]
+        dist.all_gather(got, torch.tensor([3.5], dtype=torch.float64, device="cuda:0"))
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put((float(x[12345].item()), float(got[0].item()), float(y[0, 7].item())))
+    dist.destroy_process_group()
+
+
+def test_rccl_loads_and_runs_collectives_next_to_the_engine_library():
+    """the "nccl" backend (= RCCL) in a process that also runs libvr2.so kernels: process-group init with device_id, an async
+    all-reduce ordered behind an engine-stream kernel, all_gather of the timing scalar and a barrier -- the calls bench.py and
+    train.py make for N > 1, here on the one GPU of the test box (world size 1: the multi-rank path needs an 8-GPU node)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(port, q))
+    p.start()
+    a, b, c = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and a == 12345.0 and b == 3.5 and c == 7.0

@@ -60,11 +60,11 @@ struct TileRegs {
 template <int HD, int NTHREADS, int KT_ = KT>
 __device__ __forceinline__ void load_tile(TileRegs<HD, NTHREADS, KT_>& t, const bf16* KA, const bf16* VA, const bf16* KB,
                                           const bf16* VB, long ldk, int hoff, int key0, int ka_row0, int ka_len, int kb_row0,
-                                          int kend) {
+                                          int kend, int tid) {
   constexpr int CPR = HD / 8;
 #pragma unroll
   for (int i = 0; i < TileRegs<HD, NTHREADS, KT_>::NCH; ++i) {
-    const int c = threadIdx.x + i * NTHREADS;
+    const int c = tid + i * NTHREADS;
     const int kr = c / CPR, ch = c % CPR;
     const int key = key0 + kr;
     bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -81,11 +81,11 @@ __device__ __forceinline__ void load_tile(TileRegs<HD, NTHREADS, KT_>& t, const 
 }
 
 template <int HD, int NTHREADS, int KT_ = KT>
-__device__ __forceinline__ void store_tile(const TileRegs<HD, NTHREADS, KT_>& t, bf16* sK, bf16* sV) {
+__device__ __forceinline__ void store_tile(const TileRegs<HD, NTHREADS, KT_>& t, bf16* sK, bf16* sV, int tid) {
   constexpr int CPR = HD / 8;
 #pragma unroll
   for (int i = 0; i < TileRegs<HD, NTHREADS, KT_>::NCH; ++i) {
-    const int c = threadIdx.x + i * NTHREADS;
+    const int c = tid + i * NTHREADS;
     if (c < KT_ * CPR) {
       const int kr = c / CPR, ch = c % CPR;
       *reinterpret_cast<bf16x8*>(sK + kr * Strides<HD>::K + ch * 8) = t.k[i];
@@ -96,6 +96,8 @@ __device__ __forceinline__ void store_tile(const TileRegs<HD, NTHREADS, KT_>& t,
 
 // One wave processes key range [kbeg, kend) for its 16 query slots.  qf: Q fragments.  vis_lim: per-lane causal
 // limit in CONCATENATED key index (key visible iff key < vis_lim && key < kend).
+// NTHREADS threads stage a tile together; NTHREADS == 64 = one wave with an LDS region of its own: no workgroup barrier (the
+// other waves of the workgroup run their own loops with their own trip counts), a wave's DS operations execute in issue order.
 template <int HD, int NTHREADS, int KT_ = KT>
 __device__ __forceinline__ void attn_loop(const s16x4* qf, float scale, int kbeg, int kend, int vis_lim, bf16* sK, bf16* sV,
                                           const bf16* KA, const bf16* VA, const bf16* KB, const bf16* VB, long ldk, int hoff,
@@ -104,14 +106,15 @@ __device__ __forceinline__ void attn_loop(const s16x4* qf, float scale, int kbeg
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fq = lane >> 4;
   constexpr int NB = KT_ / 16;   // 16-key blocks per LDS tile
+  const int tid = NTHREADS == 64 ? lane : (int)threadIdx.x;
   TileRegs<HD, NTHREADS, KT_> tr;
-  load_tile<HD, NTHREADS, KT_>(tr, KA, VA, KB, VB, ldk, hoff, kbeg, ka_row0, ka_len, kb_row0, kend);
+  load_tile<HD, NTHREADS, KT_>(tr, KA, VA, KB, VB, ldk, hoff, kbeg, ka_row0, ka_len, kb_row0, kend, tid);
   for (int key0 = kbeg; key0 < kend; key0 += KT_) {
-    __syncthreads();  // previous tile fully consumed
-    store_tile<HD, NTHREADS, KT_>(tr, sK, sV);
-    __syncthreads();
+    if constexpr (NTHREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();  // previous tile fully consumed
+    store_tile<HD, NTHREADS, KT_>(tr, sK, sV, tid);
+    if constexpr (NTHREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     if (key0 + KT_ < kend)   // next tile's loads fly under this tile's MFMAs
-      load_tile<HD, NTHREADS, KT_>(tr, KA, VA, KB, VB, ldk, hoff, key0 + KT_, ka_row0, ka_len, kb_row0, kend);
+      load_tile<HD, NTHREADS, KT_>(tr, KA, VA, KB, VB, ldk, hoff, key0 + KT_, ka_row0, ka_len, kb_row0, kend, tid);
     f32x4 s[NB];
     float mx = -INFINITY;
 #pragma unroll
@@ -223,17 +226,14 @@ __global__ __launch_bounds__(256) void attn_tok_kernel(const AttnWork* __restric
 // prefix keys, so ONE workgroup stages a key chunk once and serves seqs_per_group x group query slots (G=8 sequences x 7 q
 // heads of one KV head = 56 slots on the 4 waves' 64): prefix K/V traffic and staging work drop by seqs_per_group.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_prefix_kernel(const bf16* __restrict__ Q, long ldq, const bf16* __restrict__ KP,
-                                                                 const bf16* __restrict__ VP, long ldk,
-                                                                 const int* __restrict__ prefix_len_dev, int seqs_per_group,
-                                                                 long prefix_group_stride, int chunk, int nslot, int slot_blocks,
-                                                                 int group, int n_heads, float scale, float* __restrict__ po,
-                                                                 float* __restrict__ pml) {
+__device__ __forceinline__ void decode_prefix_body(bf16* sK, bf16* sV, int c, int kvh, int bz, const bf16* __restrict__ Q, long ldq,
+                                                   const bf16* __restrict__ KP, const bf16* __restrict__ VP, long ldk,
+                                                   const int* __restrict__ prefix_len_dev, int seqs_per_group,
+                                                   long prefix_group_stride, int chunk, int nslot, int slot_blocks, int group,
+                                                   int n_heads, float scale, float* __restrict__ po, float* __restrict__ pml) {
   constexpr int KTP = VR2_KTP;
-  __shared__ __attribute__((aligned(16))) bf16 sK[KTP * Strides<HD>::K];
-  __shared__ __attribute__((aligned(16))) bf16 sV[KTP * Strides<HD>::V];
   constexpr int NKS = HD / 16;
-  const int c = blockIdx.x, kvh = blockIdx.y, grp = blockIdx.z / slot_blocks, sb = blockIdx.z % slot_blocks;
+  const int grp = bz / slot_blocks, sb = bz % slot_blocks;
   const int prefix_len = prefix_len_dev[grp];
   const int kbeg = c * chunk;
   if (kbeg >= prefix_len) return;                       // uniform over the workgroup
@@ -270,17 +270,14 @@ __global__ __launch_bounds__(256) void attn_decode_prefix_kernel(const bf16* __r
 // Suffix chunks, grid (nsc, n_kv_heads, G), one wave: the keys a sequence generated itself (unique per sequence); slots =
 // the q heads of one KV head.
 template <int HD>
-__global__ __launch_bounds__(64) void attn_decode_suffix_kernel(const bf16* __restrict__ Q, long ldq, const bf16* __restrict__ KS,
-                                                                const bf16* __restrict__ VS, long ldk, long rows_per_seq,
-                                                                const int* __restrict__ step, int chunk, int npc, int nslot,
-                                                                int group, int n_heads, float scale, float* __restrict__ po,
-                                                                float* __restrict__ pml) {
-  constexpr int KTS = VR2_KTS;   // 16-key LDS tiles (9 KiB per single-wave workgroup), loaded one tile ahead: 44.2 / 38.7 / 36.8 us per
-                                 // layer for 64- / 32- / 16-key tiles at 128 sequences, C = 1024, 256-key chunks
-  __shared__ __attribute__((aligned(16))) bf16 sK[KTS * Strides<HD>::K];
-  __shared__ __attribute__((aligned(16))) bf16 sV[KTS * Strides<HD>::V];
+__device__ __forceinline__ void decode_suffix_body(bf16* sK, bf16* sV, int c, int kvh, int g, const bf16* __restrict__ Q, long ldq,
+                                                   const bf16* __restrict__ KS, const bf16* __restrict__ VS, long ldk,
+                                                   long rows_per_seq, const int* __restrict__ step, int chunk, int npc, int nslot,
+                                                   int group, int n_heads, float scale, float* __restrict__ po,
+                                                   float* __restrict__ pml) {
+  constexpr int KTS = VR2_KTS;   // 16-key LDS tiles (9 KiB per wave), loaded one tile ahead: 44.2 / 38.7 / 36.8 us per layer for
+                                 // 64- / 32- / 16-key tiles at 128 sequences, C = 1024, 256-key chunks
   constexpr int NKS = HD / 16;
-  const int c = blockIdx.x, kvh = blockIdx.y, g = blockIdx.z;
   const int total = step[0] + 1;
   const int kbeg = c * chunk;
   if (kbeg >= total) return;
@@ -308,6 +305,38 @@ __global__ __launch_bounds__(64) void attn_decode_suffix_kernel(const bf16* __re
   float* op = po + pslot * HD + fq * 4;
 #pragma unroll
   for (int db = 0; db < NKS; ++db) *reinterpret_cast<float4*>(op + db * 16) = make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
+}
+
+// ONE launch for both: workgroups [0, n_suffix_blocks) take four suffix items each (one per wave, wave-local LDS tiles, no
+// workgroup barrier), the rest are prefix workgroups.  The two parts read disjoint caches and write disjoint partial slots; in
+// one grid they share the chip instead of running one after the other (prefix alone: P x n_kv x chunks short workgroups;
+// suffix alone: a tail of single waves), and a launch boundary per layer goes away.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict__ Q, long ldq, const bf16* __restrict__ KP,
+                                                          const bf16* __restrict__ VP, const bf16* __restrict__ KS,
+                                                          const bf16* __restrict__ VS, long ldk, const int* __restrict__ prefix_len_dev,
+                                                          int seqs_per_group, long prefix_group_stride, long rows_per_seq,
+                                                          const int* __restrict__ step, int schunk, int pchunk, int npc, int nsc,
+                                                          int n_suffix_blocks, int n_kv, int G, int slot_blocks, int group,
+                                                          int n_heads, float scale, float* __restrict__ po, float* __restrict__ pml) {
+  constexpr int KTP = VR2_KTP, KTS = VR2_KTS;
+  static_assert(KTP >= 4 * KTS, "four suffix waves share the prefix tile's LDS");
+  __shared__ __attribute__((aligned(16))) bf16 sK[KTP * Strides<HD>::K];
+  __shared__ __attribute__((aligned(16))) bf16 sV[KTP * Strides<HD>::V];
+  const int nslot = npc + nsc;
+  if ((int)blockIdx.x < n_suffix_blocks) {
+    const int wave = threadIdx.x >> 6;
+    const int item = (int)blockIdx.x * 4 + wave;           // (g, kvh, c), c fastest: the live chunks of a sequence sit together
+    if (item >= nsc * n_kv * G) return;
+    const int c = item % nsc, kvh = (item / nsc) % n_kv, g = item / (nsc * n_kv);
+    decode_suffix_body<HD>(sK + wave * KTS * Strides<HD>::K, sV + wave * KTS * Strides<HD>::V, c, kvh, g, Q, ldq, KS, VS, ldk, rows_per_seq,
+                           step, schunk, npc, nslot, group, n_heads, scale, po, pml);
+  } else {
+    const int b = (int)blockIdx.x - n_suffix_blocks;
+    const int c = b % npc, kvh = (b / npc) % n_kv, bz = b / (npc * n_kv);
+    decode_prefix_body<HD>(sK, sV, c, kvh, bz, Q, ldq, KP, VP, ldk, prefix_len_dev, seqs_per_group, prefix_group_stride, pchunk, nslot,
+                           slot_blocks, group, n_heads, scale, po, pml);
+  }
 }
 
 // combine the chunk partials: out[g][head][:] bf16.  One wave per (head, sequence); the chunks that are live at this step are
@@ -415,16 +444,15 @@ extern "C" int vr2_attn_decode(const void* Q, int64_t ldq, const void* Kprefix, 
   const int npc = (int)n_prefix_chunks, nslot = (int)(n_prefix_chunks + n_suffix_chunks);
   const int slot_blocks = (int)((seqs_per_group * group + 63) / 64);
   const unsigned n_kv = (unsigned)(n_heads / group);
-  hipLaunchKernelGGL(attn_decode_prefix_kernel<128>, dim3((unsigned)npc, n_kv, (unsigned)((G / seqs_per_group) * slot_blocks)),
-                     dim3(256), 0, s, (const bf16*)Q, (long)ldq, (const bf16*)Kprefix, (const bf16*)Vprefix, (long)ldk,
-                     (const int*)prefix_len_i32, (int)seqs_per_group, (long)prefix_group_stride, (int)prefix_chunk, nslot, slot_blocks,
-                     (int)group, (int)n_heads, scale, (float*)part_o_f32, (float*)part_ml_f32);
-  if (vr2_check_launch("vr2_attn_decode(prefix)")) return -1;
-  hipLaunchKernelGGL(attn_decode_suffix_kernel<128>, dim3((unsigned)n_suffix_chunks, n_kv, (unsigned)G), dim3(64), 0, s,
-                     (const bf16*)Q, (long)ldq, (const bf16*)Ksuffix, (const bf16*)Vsuffix, (long)ldk, (long)rows_per_seq,
-                     (const int*)step_i32, (int)chunk, npc, nslot, (int)group, (int)n_heads, scale, (float*)part_o_f32,
-                     (float*)part_ml_f32);
-  if (vr2_check_launch("vr2_attn_decode(suffix)")) return -1;
+  const int P = (int)(G / seqs_per_group);
+  const int n_suffix_items = (int)n_suffix_chunks * (int)n_kv * (int)G, n_suffix_blocks = (n_suffix_items + 3) / 4;
+  const int n_prefix_blocks = npc * (int)n_kv * P * slot_blocks;
+  hipLaunchKernelGGL(attn_decode_kernel<128>, dim3((unsigned)(n_suffix_blocks + n_prefix_blocks)), dim3(256), 0, s, (const bf16*)Q, (long)ldq,
+                     (const bf16*)Kprefix, (const bf16*)Vprefix, (const bf16*)Ksuffix, (const bf16*)Vsuffix, (long)ldk,
+                     (const int*)prefix_len_i32, (int)seqs_per_group, (long)prefix_group_stride, (long)rows_per_seq, (const int*)step_i32,
+                     (int)chunk, (int)prefix_chunk, npc, (int)n_suffix_chunks, n_suffix_blocks, (int)n_kv, (int)G, slot_blocks, (int)group,
+                     (int)n_heads, scale, (float*)part_o_f32, (float*)part_ml_f32);
+  if (vr2_check_launch("vr2_attn_decode(prefix + suffix)")) return -1;
   hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)n_heads, (unsigned)G), dim3(64), 0, s, (const float*)part_o_f32,
                      (const float*)part_ml_f32, npc, nslot, (int)head_dim, (bf16*)out_bf16, (long)ldo, (int)n_heads,
                      (const int*)prefix_len_i32, (int)seqs_per_group, (const int*)step_i32, (int)chunk, (int)prefix_chunk);

@@ -615,7 +615,10 @@ class Engine:
             return want
         # (M <= 16: 32-row workgroups with 4 k-splitting waves; M > 16: the LDS-staged variant covers 128 output rows per
         # workgroup with 2 k groups -> the same slab count for q/k/v and o, twice for down)
-        wq, wd = (4, 4) if G <= 16 else (4, 8) if G <= 64 else (7, 8)   # 128 rows: 7 parts of 4 chunks (6.47 -> 6.37 ms/token)
+        wq, wd = (4, 4) if G <= 16 else (4, 8)     # ring kernel at 128 rows, (q/o parts, down parts): (7,8) 4.84, (4,8) 4.72-4.77,
+                                                    # (4,4) 5.03, (2,4) 5.20, (4,10) 4.70, (5,8) 4.73 ms/token (C = 256)
+        if os.environ.get("VR2_SPLITS"):                               # measurement override: "q,d"
+            wq, wd = (int(v) for v in os.environ["VR2_SPLITS"].split(","))
         if self.decode_fp8 and G <= self.decode_fp8_max_rows:
             # fp8 weights: 64-k double steps (direct kernel) / 256-k chunks (staged kernel, no second k group): fewer, longer parts
             def pick(k, want):                     # noqa: F811

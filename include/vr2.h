@@ -192,16 +192,19 @@ int vr2_colsum_bf16(const void* a_bf16, int64_t lda, void* out_f32, int64_t M, i
 int vr2_rope_bwd(const void* dq_bf16, int64_t ldq, const void* dk_f32, const void* dv_f32, int64_t ldkv, const void* cos_f32,
                  const void* sin_f32, int64_t T, int64_t nq, int64_t nkv, int64_t head_dim, void* dqkv_bf16, int64_t ld,
                  void* stream);
-/* flash-style attention backward (head_dim 128): delta = rowsum(dO o O); dQ query-centric; dK/dV key-centric into ZEROED fp32
- * buffers (work items add their share).  key work item (8 x int32): k_row0, nk, q1_row0, q1_len (causal: key row <= query
- * row), q2_row0, q2_len (all visible), pad, pad -- a long all-visible range is split over several items by the host */
+/* flash-style attention backward (head_dim 128).  vr2_attn_delta: rowc_f32 [2][n_heads][T] = the per-row constants, transposed:
+ * rowc[0][h][t] = -lse[t][h] * log2(e), rowc[1][h][t] = delta = rowsum(dO o O).  dQ query-centric (work items as vr2_attn_tok,
+ * up to 128 query rows each); dK/dV key-centric into ZEROED fp32 buffers (work items add their share).  key work item
+ * (8 x int32): k_row0, nk (<= 128), q1_row0, q1_len (causal: key row <= query row), q2_row0, q2_len (all visible), head0,
+ * nheads (the q heads head0 .. head0 + nheads - 1 of the KV head's GQA group; nheads = 0: the whole group) -- a long sweep is
+ * split over several items by the host, by query range and / or by heads */
 int vr2_attn_delta(const void* O_bf16, const void* dO_bf16, int64_t ld, int64_t T, int64_t n_heads, int64_t head_dim,
-                   void* delta_f32, void* stream);
+                   const void* lse_f32, void* rowc_f32, void* stream);
 int vr2_attn_bwd_dq(const void* work_i32x8, int64_t n_work, const void* Q, int64_t ldq, const void* KA, const void* VA,
-                    const void* KB, const void* VB, int64_t ldk, const void* dO, const void* lse_f32, const void* delta_f32,
+                    const void* KB, const void* VB, int64_t ldk, const void* dO, const void* rowc_f32, int64_t T,
                     void* dQ, int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* stream);
 int vr2_attn_bwd_dkv(const void* keywork_i32x8, int64_t n_work, const void* Q, int64_t ldq, const void* K, const void* V,
-                     int64_t ldk, const void* dO, const void* lse_f32, const void* delta_f32, void* dK_f32, void* dV_f32,
+                     int64_t ldk, const void* dO, const void* rowc_f32, int64_t T, void* dK_f32, void* dV_f32,
                      int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* stream);
 /* dz = dlogp/T * (onehot(tok) - softmax(z/T)) as bf16 rows (log-prob head backward, grpo_trainer.py:738-739) */
 int vr2_dlogits(const void* logits_f32, int64_t ldl, int64_t R, int64_t V, const void* tok_i32, const void* lse_f32,

@@ -137,11 +137,12 @@ def test_dlogits_embed_bwd_colsum(dev):
     assert (cs.cpu() - a.float().sum(0)).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("group", [2, 7])
-def test_attention_backward_vs_autograd(dev, group):
+@pytest.mark.parametrize("group,Sp,C,G,ktile,qsplit", [(2, 70, 40, 2, 128, 48), (7, 70, 40, 2, 64, 48), (7, 300, 200, 3, 128, 256),
+                                                       (4, 256, 128, 2, 128, 128)])
+def test_attention_backward_vs_autograd(dev, group, Sp, C, G, ktile, qsplit):
     """Unified rows: S prompt rows (causal) + G sequences of C completion rows (prefix visible + own causal), GQA."""
     from video_r2_amd.host import vision_plan as vp
-    hd, nKV, Sp, C, G = 128, 2, 70, 40, 2
+    hd, nKV = 128, 2
     nH = nKV * group
     T = Sp + G * C
     scale = hd ** -0.5
@@ -171,13 +172,21 @@ def test_attention_backward_vs_autograd(dev, group):
     lib.call("vr2_attn_tok", dwork, dwork.shape[0], qd, nH * hd, kd, vd, kd, vd, nKV * hd, od, nH * hd, nH, group, hd, scale, lse, S())
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-3
     dod = bf(do).view(T, -1).to(dev)
-    delta = torch.zeros(T, nH, device=dev)
-    lib.call("vr2_attn_delta", od, dod, nH * hd, T, nH, hd, delta, S())
+    rowc = torch.zeros(2, nH, T, device=dev)
+    lib.call("vr2_attn_delta", od, dod, nH * hd, T, nH, hd, lse, rowc, S())
+    delta_ref = (o.detach() * do).sum(-1)                                        # [T][nH]
+    assert (rowc[1].t().cpu() - delta_ref).abs().max().item() < 2e-2 * delta_ref.abs().max().item()
+    assert torch.allclose(rowc[0].t().cpu(), -lse.cpu() * 1.4426950408889634, rtol=1e-6, atol=1e-6)
+    work_dq = np.concatenate([vp.causal_work(Sp, 0, 0, 0, 0, q_tile=128)] +
+                             [vp.causal_work(C, Sp + gg * C, 0, Sp, Sp + gg * C, q_tile=128) for gg in range(G)])
+    dwq = torch.from_numpy(work_dq).to(dev)
     dq = torch.zeros(T, nH * hd, dtype=torch.bfloat16, device=dev)
-    lib.call("vr2_attn_bwd_dq", dwork, dwork.shape[0], qd, nH * hd, kd, vd, kd, vd, nKV * hd, dod, lse, delta, dq, nH, group, hd, scale, S())
-    kw = torch.from_numpy(vp.key_work(Sp, G, C, q_split=48)).to(dev)      # small split: several adders per prompt key row
+    lib.call("vr2_attn_bwd_dq", dwq, dwq.shape[0], qd, nH * hd, kd, vd, kd, vd, nKV * hd, dod, rowc, T, dq, nH, group, hd, scale, S())
+    # small splits: several adders per prompt key row, by query range and by q heads
+    kw = torch.from_numpy(vp.key_work(Sp, G, C, k_tile=ktile, q_split=qsplit, group=group, max_steps=3)).to(dev)
+    assert (kw[:, 7] < group).any().item()                                   # some items cover only part of the GQA group
     dk = torch.zeros(T, nKV * hd, dtype=torch.float32, device=dev); dv = torch.zeros_like(dk)
-    lib.call("vr2_attn_bwd_dkv", kw, kw.shape[0], qd, nH * hd, kd, vd, nKV * hd, dod, lse, delta, dk, dv, nH, group, hd, scale, S())
+    lib.call("vr2_attn_bwd_dkv", kw, kw.shape[0], qd, nH * hd, kd, vd, nKV * hd, dod, rowc, T, dk, dv, nH, group, hd, scale, S())
     # bf16 P / dS operands and bf16 outputs: 2^-6 of each gradient's scale
     for got, ref, name in ((dq, q.grad.view(T, -1), "dq"), (dk, k.grad.view(T, -1), "dk"), (dv, v.grad.view(T, -1), "dv")):
         e = (got.float().cpu() - ref).abs().max().item() / ref.abs().max().item()

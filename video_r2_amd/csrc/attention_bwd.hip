@@ -1,44 +1,237 @@
 // Attention backward for the LM update path, flash-style: P is recomputed from Q, K and the forward's
-// log-sum-exp, nothing of size S x S is stored.  Two kernels:
-//   * vr2_attn_bwd_dq  : query-centric, the forward kernel's structure (work items, 16 query slots per wave, K/V tiles in
-//                        LDS): dS^T = P^T o (V dO^T - delta), dQ^T += K^T dS^T.
-//   * vr2_attn_bwd_dkv : key-centric: a workgroup holds 64 keys of one KV head (K^T / V^T fragments in registers) and walks
-//                        a range of query tiles that can see them and all q heads of the GQA group: dV^T += dO^T P,
-//                        dK^T += Q^T dS.  Prompt keys are seen by every completion row of all G sequences (G*C rows), so
-//                        that range is SPLIT over several workgroups (host work list) and dK/dV are fp32 buffers the
-//                        workgroups add into (few, large, contiguous 16-B-per-lane fp32 atomics: <= 9 adders per element).
+// log-sum-exp, nothing of size S x S is stored.  Two kernels, both one wave per SIMD (4 waves, the whole register file):
+//   * vr2_attn_bwd_dkv : key-centric.  A workgroup holds 128 keys of one KV head -- every wave 32 keys, K / V fragments and the
+//                        dK^T / dV^T accumulators of those keys in registers -- and sweeps (q heads of the GQA group) x (64-row
+//                        query tiles that can see them): S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.  Prompt keys
+//                        are seen by every completion row of all G sequences, so that sweep is SPLIT over several workgroups
+//                        (host work list) and dK / dV are fp32 buffers the workgroups add into (whole 256-byte row segments
+//                        per wave-instruction, the shape the memory-side float atomics run at full rate with).
+//   * vr2_attn_bwd_dq  : query-centric.  A workgroup holds 128 query rows of one head (32 per wave: Q / dO fragments and dQ^T
+//                        in registers) and sweeps the 64-key tiles it can see: S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T.
 // Unified row space: rows [0,S) are the prompt, rows S + g*C + j completion token j of sequence g; Q/K/V/O/dO are row-major
-// [T][heads*hd] bf16, LSE / delta are [T][n_heads] fp32.  All MFMAs are v_mfma_f32_16x16x16_bf16 with the same
-// "lane owns 4 consecutive rows of one column" accumulator layout as the forward, so P / dS feed the next MFMA from
-// registers; transposed operands come from row-major LDS tiles via ds_read_b64_tr_b16.
+// [T][heads*128] bf16.  Per-row constants come TRANSPOSED from vr2_attn_delta: rowc[0][head][t] = -LSE * log2(e),
+// rowc[1][head][t] = delta = rowsum(dO o O), so that p = exp2(scale*log2(e) * s + rowc[0]) needs no row maximum.
+//
+// The swept tiles (Q and dO, or K and V: 64 rows x 256 B) arrive by direct-to-LDS loads (one 1-KiB piece = 4 rows per wave
+// instruction) in a ring, counted vmcnt, one barrier per tile.  LDS image of a tile: plain 256-byte rows whose 16-byte chunks are
+// XOR-swizzled with ((row & 3) << 2) | ((row >> 2) & 3) -- applied to the per-lane SOURCE address of the load and again to the
+// read address -- so that ONE image serves the row reads (ds_read_b128, operand of S / dP) and the transposed reads
+// (ds_read_b64_tr_b16, operand of the dK / dV / dQ products) without bank conflicts.  All MFMAs are
+// v_mfma_f32_16x16x32_bf16.  MFMA row i of a 16-row block b of a 32-row half stands for tile row (i & 3) + 8 (i >> 2) + 4 b:
+// the accumulators of blocks 0 and 1 then hold, per lane, 8 CONSECUTIVE rows 8 (lane >> 4) .. + 7 of the half, which is exactly
+// the k order the next MFMA's B operand wants, so P and dS feed it from registers.
+#include <type_traits>
 #include "common.h"
 
 namespace {
 
 struct AttnWork { int q_row0, nq, ka_row0, ka_len, kb_row0, kb_len, q_causal0, pad; };
-struct KeyWork { int k_row0, nk, q1_row0, q1_len, q2_row0, q2_len, pad0, pad1; };  // q1: causal (key row <= query row); q2: all visible
+struct KeyWork { int k_row0, nk, q1_row0, q1_len, q2_row0, q2_len, head0, nheads; };  // q1: causal (key row <= query row); q2: all visible
 
-constexpr int KT = 64;
-constexpr int STR_T = 144;   // elements/row (288 B): conflict-free for tr reads, 2-way for b64 row reads
-constexpr int STR_R = 136;   // elements/row (272 B): conflict-free for b64 row reads
-constexpr int HD = 128, NKS = HD / 16;
+constexpr int HD = 128;
+constexpr int TILE_B = 64 * 256;                 // one swept tile: 64 rows x 256 B
+constexpr int ROWC_B = 512;                      // dkv: 4 waves x [16 x -lse*log2e | 16 x delta] fp32
+constexpr int KV_STAGE_B = 2 * TILE_B + ROWC_B;  // dkv ring stage: Q tile | dO tile | row constants
+constexpr int KV_NSTAGE = 3;
+constexpr int DQ_STAGE_B = 2 * TILE_B;           // dq ring stage: K tile | V tile
+constexpr int DQ_NSTAGE = 2;
+constexpr int OUT_STRIDE = 132;                  // fp32 words per staged output row (528 B: conflict-free 16-byte writes)
+constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ s16x4 tr_read(const bf16* p) {
+__device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// A operand read by rows: MFMA row i = tile row 32 h + (i & 3) + 8 (i >> 2) + 4 b, k = features 32 ks + 8 fq .. + 7
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int h, int b, int ks, int lane) {
+  const int i = lane & 15, fq = lane >> 4;
+  const int row = 32 * h + (i & 3) + 8 * (i >> 2) + 4 * b;
+  return *reinterpret_cast<const bf16x8*>(tile + img_off(row, ks * 4 + fq));
+}
+// A operand read transposed: MFMA row i = feature 16 db + i, k = tile rows 32 h + 8 fq .. + 7 (two 4-row blocks)
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int h, int db, int lane) {
   typedef __attribute__((ext_vector_type(4))) __bf16 vb4;
-  vb4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) vb4*)(p));
-  return __builtin_bit_cast(s16x4, t);
+  const int fq = lane >> 4, a = (lane & 15) >> 2, p = lane & 3;
+  const int row = 32 * h + 8 * fq + a, ch = db * 2 + (p >> 1);
+  const vb4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) vb4*)(tile + img_off(row, ch) + 8 * (p & 1)));
+  const vb4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) vb4*)(tile + img_off(row + 4, ch) + 8 * (p & 1)));
+  bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return r;
 }
 
-// delta[t][h] = sum_d dO[t][h][d] * O[t][h][d]
+// delta[t][h] = sum_d dO[t][h][d] * O[t][h][d];  rowc[0][h][t] = -lse[t][h] * log2(e), rowc[1][h][t] = delta
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, long ld, int n_heads,
-                                                         float* __restrict__ delta) {
+                                                         const float* __restrict__ lse, float* __restrict__ rowc, long T) {
   const int t = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int h = wave; h < n_heads; h += 4) {
     const long off = (long)t * ld + (long)h * HD + lane * 2;
     float v = bf2f(O[off]) * bf2f(dO[off]) + bf2f(O[off + 1]) * bf2f(dO[off + 1]);
     v = wave_sum(v);
-    if (lane == 0) delta[(long)t * n_heads + h] = v;
+    if (lane == 0) {
+      rowc[(long)h * T + t] = -lse[(long)t * n_heads + h] * LOG2E;
+      rowc[((long)n_heads + h) * T + t] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const KeyWork* __restrict__ work, const bf16* __restrict__ Q, long ldq,
+                                                           const bf16* __restrict__ K, const bf16* __restrict__ V, long ldk,
+                                                           const bf16* __restrict__ dO, const float* __restrict__ rowc, long T,
+                                                           float* __restrict__ dK, float* __restrict__ dV, int n_heads, int group,
+                                                           float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const KeyWork w = work[blockIdx.x];
+  const int kvh = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nh = w.nheads > 0 ? w.nheads : group, head_first = kvh * group + w.head0;
+  const int n1 = (w.q1_len + 63) >> 6, n2 = (w.q2_len + 63) >> 6, per_head = n1 + n2, nsteps = nh * per_head;
+  bf16x8 kf[2][4], vf[2][4];
+  bool kvalid[2];
+  int krow[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int slot = wave * 32 + s * 16 + fr;
+    kvalid[s] = slot < w.nk;
+    krow[s] = w.k_row0 + (kvalid[s] ? slot : w.nk - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[s][ks] = *reinterpret_cast<const bf16x8*>(K + (long)krow[s] * ldk + kvh * HD + ks * 32 + fq * 8);
+      vf[s][ks] = *reinterpret_cast<const bf16x8*>(V + (long)krow[s] * ldk + kvh * HD + ks * 32 + fq * 8);
+    }
+  }
+  // consume the fragments here: the compiler waits for these loads now instead of inside the loop, where its (uncounted-for)
+  // s_waitcnt vmcnt would also drain the ring's direct-to-LDS loads
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(kf[s][ks]), "v"(vf[s][ks]));
+  f32x4 accK[2][8], accV[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { accK[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[s][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float c2 = scale * LOG2E;
+
+  struct Step { int head, r0, rl, q0; bool causal; };
+  auto decode = [&](int st) {
+    Step d;
+    const int hq = st / per_head, t = st - hq * per_head;
+    d.head = head_first + hq;
+    d.causal = t < n1;
+    d.r0 = d.causal ? w.q1_row0 : w.q2_row0;
+    d.rl = d.causal ? w.q1_len : w.q2_len;
+    d.q0 = (d.causal ? t : t - n1) * 64;
+    return d;
+  };
+  auto issue = [&](int st) {   // 9 direct-to-LDS loads per wave
+    const Step d = decode(st);
+    char* stg = smem + (st % KV_NSTAGE) * KV_STAGE_B;
+    const int rmax = d.rl - 1 - d.q0;   // rows past the range re-read its last row (masked out of P)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pi = wave * 4 + j;
+      int row = pi * 4 + (lane >> 4);
+      const int sc = (lane & 15) ^ (((lane >> 4) << 2) | j);   // (row & 3) = lane >> 4, (row >> 2) & 3 = j
+      row = row < rmax ? row : rmax;
+      const long off = (long)(d.r0 + d.q0 + row) * ldq + (long)d.head * HD + sc * 8;
+      vr2_dma16(Q + off, stg + pi * 1024);
+      vr2_dma16(dO + off, stg + TILE_B + pi * 1024);
+    }
+    {
+      int row = wave * 16 + (lane & 15);
+      row = row < rmax ? row : rmax;
+      const float* src = rowc + ((long)((lane >> 4) & 1) * n_heads + d.head) * T + d.r0 + d.q0 + row;
+      if (lane < 32) vr2_dma4(src, stg + 2 * TILE_B + wave * 128);
+    }
+  };
+  auto compute = [&](int st, auto masked_tag) {
+    constexpr bool MASK = decltype(masked_tag)::value;
+    const Step d = decode(st);
+    const char* sQ = smem + (st % KV_NSTAGE) * KV_STAGE_B;
+    const char* sD = sQ + TILE_B;
+    const float* sR = reinterpret_cast<const float*>(sQ + 2 * TILE_B);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 sa[2][2], da[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { sa[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; da[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const bf16x8 aq = row_frag(sQ, h, b, ks, lane), ad = row_frag(sD, h, b, ks, lane);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            sa[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, kf[s][ks], sa[b][s], 0, 0, 0);
+            da[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, vf[s][ks], da[b][s], 0, 0, 0);
+          }
+        }
+      // lane: key slot fr of both key sets (column), tile rows 32 h + 8 fq + 4 b + r
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int rb = 32 * h + 8 * fq + 4 * b;
+        const f32x4 nl = *reinterpret_cast<const f32x4*>(sR + (rb >> 4) * 32 + (rb & 15));
+        const f32x4 dl = *reinterpret_cast<const f32x4*>(sR + (rb >> 4) * 32 + 16 + (rb & 15));
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(c2 * sa[b][s][r] + nl[r]);
+            if (MASK) {
+              const int ql = d.q0 + rb + r;
+              const bool ok = kvalid[s] && ql < d.rl && (!d.causal || krow[s] <= d.r0 + ql);
+              p = ok ? p : 0.f;
+            }
+            pb[s][4 * b + r] = f2bf(p);
+            dsb[s][4 * b + r] = f2bf(p * (da[b][s][r] - dl[r]));
+          }
+      }
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        const bf16x8 ad = tr_frag(sD, h, db, lane), aq = tr_frag(sQ, h, db, lane);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          accV[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, pb[s], accV[s][db], 0, 0, 0);
+          accK[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, dsb[s], accK[s][db], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  if (nsteps > 0) issue(0);
+  if (nsteps > 1) issue(1);
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (st + 2 < nsteps) issue(st + 2);
+    const Step d = decode(st);
+    const bool masked = (d.causal && d.r0 + d.q0 < w.k_row0 + w.nk - 1) || (d.q0 + 64 > d.rl) || w.nk < 128;
+    if (masked) compute(st, std::true_type{});
+    else compute(st, std::false_type{});
+  }
+  // epilogue: every wave transposes its 32 key rows through LDS and adds whole 256-byte row segments
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float* stg = reinterpret_cast<float*>(smem) + wave * 32 * OUT_STRIDE;
+  const int nrows = (w.nk - wave * 32) < 32 ? (w.nk - wave * 32) : 32;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float* dst = (pass == 0 ? dK : dV) + (long)(w.k_row0 + wave * 32) * ldk + kvh * HD;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        f32x4 v = pass == 0 ? accK[s][db] : accV[s][db];
+        if (pass == 0) { v[0] *= scale; v[1] *= scale; v[2] *= scale; v[3] *= scale; }
+        *reinterpret_cast<f32x4*>(stg + (s * 16 + fr) * OUT_STRIDE + db * 16 + 4 * fq) = v;
+      }
+    for (int rr = 0; rr < nrows; ++rr) {
+      unsafeAtomicAdd(dst + (long)rr * ldk + lane, stg[rr * OUT_STRIDE + lane]);
+      unsafeAtomicAdd(dst + (long)rr * ldk + 64 + lane, stg[rr * OUT_STRIDE + 64 + lane]);
+    }
   }
 }
 
@@ -46,192 +239,134 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnWork* __restrict__ work, const bf16* __restrict__ Q, long ldq,
                                                           const bf16* __restrict__ KA, const bf16* __restrict__ VA,
                                                           const bf16* __restrict__ KB, const bf16* __restrict__ VB, long ldk,
-                                                          const bf16* __restrict__ dO, const float* __restrict__ LSE,
-                                                          const float* __restrict__ DELTA, bf16* __restrict__ dQ, int n_heads,
-                                                          int group, float scale) {
-  __shared__ __attribute__((aligned(16))) bf16 sK[KT * STR_T];   // row reads (S) and transposed reads (dQ)
-  __shared__ __attribute__((aligned(16))) bf16 sV[KT * STR_R];   // row reads (dP)
+                                                          const bf16* __restrict__ dO, const float* __restrict__ rowc, long T,
+                                                          bf16* __restrict__ dQ, int n_heads, int group, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnWork w = work[blockIdx.x];
   const int head = blockIdx.y, kvh = head / group;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int qi = wave * 16 + fr;
-  const bool qvalid = qi < w.nq;
-  const long qrow = w.q_row0 + (qvalid ? qi : 0);
-  s16x4 qf[NKS], df[NKS];
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    qf[ks] = *reinterpret_cast<const s16x4*>(Q + qrow * ldq + (long)head * HD + ks * 16 + fq * 4);
-    df[ks] = *reinterpret_cast<const s16x4*>(dO + qrow * ldq + (long)head * HD + ks * 16 + fq * 4);
-  }
-  const float lse = LSE[qrow * n_heads + head], delta = DELTA[qrow * n_heads + head];
+  bf16x8 qf[2][4], df[2][4];
+  float nls[2], dl[2];
+  int vis_lim[2];
   long lastq = (long)w.q_causal0 + (w.nq - 1) + 1;
   const int bvis = (int)(lastq < w.kb_len ? lastq : w.kb_len);
   const int kend = w.ka_len + (bvis > 0 ? bvis : 0);
-  long lim = (long)w.ka_len + (long)w.q_causal0 + qi + 1;
-  const int vis_lim = qvalid ? (int)(lim < kend ? lim : kend) : 0;
-  f32x4 acc[NKS];
 #pragma unroll
-  for (int i = 0; i < NKS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int hoff = kvh * HD;
-  for (int key0 = 0; key0 < kend; key0 += KT) {
-    __syncthreads();
-    for (int c = threadIdx.x; c < KT * 16; c += 256) {
-      const int kr = c >> 4, ch = c & 15;
-      const int key = key0 + kr;
-      bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-      if (key < kend) {
-        const bool inA = key < w.ka_len;
-        const long row = inA ? (long)(w.ka_row0 + key) : (long)(w.kb_row0 + key - w.ka_len);
-        kv = *reinterpret_cast<const bf16x8*>((inA ? KA : KB) + row * ldk + hoff + ch * 8);
-        vv = *reinterpret_cast<const bf16x8*>((inA ? VA : VB) + row * ldk + hoff + ch * 8);
-      }
-      *reinterpret_cast<bf16x8*>(sK + kr * STR_T + ch * 8) = kv;
-      *reinterpret_cast<bf16x8*>(sV + kr * STR_R + ch * 8) = vv;
+  for (int s = 0; s < 2; ++s) {
+    const int qi = wave * 32 + s * 16 + fr;
+    const bool qvalid = qi < w.nq;
+    const long qrow = w.q_row0 + (qvalid ? qi : w.nq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[s][ks] = *reinterpret_cast<const bf16x8*>(Q + qrow * ldq + (long)head * HD + ks * 32 + fq * 8);
+      df[s][ks] = *reinterpret_cast<const bf16x8*>(dO + qrow * ldq + (long)head * HD + ks * 32 + fq * 8);
     }
-    __syncthreads();
-    s16x4 ds[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      const bf16* kp = sK + (b * 16 + fr) * STR_T + fq * 4;
-      const bf16* vp = sV + (b * 16 + fr) * STR_R + fq * 4;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(kp + ks * 16), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(vp + ks * 16), df[ks], dp, 0, 0, 0);
-      }
-      bf16x4 d4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = key0 + b * 16 + fq * 4 + r;
-        const bool ok = (key < vis_lim) && (key < kend);
-        const float p = ok ? __expf(s[r] * scale - lse) : 0.f;
-        d4[r] = f2bf(p * (dp[r] - delta) * scale);
-      }
-      ds[b] = __builtin_bit_cast(s16x4, d4);
-    }
-#pragma unroll
-    for (int db = 0; db < NKS; ++db) {
-      f32x4 o = acc[db];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const bf16* kt = sK + (b * 16 + fq * 4 + (fr >> 2)) * STR_T + db * 16 + (fr & 3) * 4;
-        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tr_read(kt), ds[b], o, 0, 0, 0);
-      }
-      acc[db] = o;
-    }
+    nls[s] = rowc[(long)head * T + qrow];
+    dl[s] = rowc[((long)n_heads + head) * T + qrow];
+    const long lim = (long)w.ka_len + (long)w.q_causal0 + qi + 1;
+    vis_lim[s] = qvalid ? (int)(lim < kend ? lim : kend) : 0;
   }
-  if (!qvalid) return;
-  bf16* op = dQ + qrow * ldq + (long)head * HD + fq * 4;
 #pragma unroll
-  for (int db = 0; db < NKS; ++db) {
-    bf16x4 o = {f2bf(acc[db][0]), f2bf(acc[db][1]), f2bf(acc[db][2]), f2bf(acc[db][3])};
-    *reinterpret_cast<bf16x4*>(op + db * 16) = o;
+  for (int s = 0; s < 2; ++s) {   // wait for the loads here, not inside the loop (see attn_bwd_dkv_kernel)
+    asm volatile("" ::"v"(nls[s]), "v"(dl[s]));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[s][ks]), "v"(df[s][ks]));
   }
-}
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[s][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float c2 = scale * LOG2E;
+  const int nsteps = (kend + 63) >> 6;
+  // the wave's lowest fully visible limit: tiles that end below it need no mask
+  int min_lim = vis_lim[0] < vis_lim[1] ? vis_lim[0] : vis_lim[1];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(min_lim, o, 64); min_lim = x < min_lim ? x : min_lim; }
 
-// ---------------------------------------------------------------- dK, dV
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const KeyWork* __restrict__ work, const bf16* __restrict__ Q, long ldq,
-                                                           const bf16* __restrict__ K, const bf16* __restrict__ V, long ldk,
-                                                           const bf16* __restrict__ dO, const float* __restrict__ LSE,
-                                                           const float* __restrict__ DELTA, float* __restrict__ dK,
-                                                           float* __restrict__ dV, int n_heads, int group, float scale) {
-  __shared__ __attribute__((aligned(16))) bf16 sQ[KT * STR_T];    // Q tile: row reads (S) + transposed reads (dK)
-  __shared__ __attribute__((aligned(16))) bf16 sD[KT * STR_T];    // dO tile: row reads (dP) + transposed reads (dV)
-  __shared__ float sL[KT], sDl[KT];
-  const KeyWork w = work[blockIdx.x];
-  const int kvh = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int kslot = wave * 16 + fr;
-  const bool kvalid = kslot < w.nk;
-  const long krow = w.k_row0 + (kvalid ? kslot : 0);
-  s16x4 kf[NKS], vf[NKS];
+  auto issue = [&](int st) {   // 8 direct-to-LDS loads per wave
+    char* stg = smem + (st % DQ_NSTAGE) * DQ_STAGE_B;
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    kf[ks] = *reinterpret_cast<const s16x4*>(K + krow * ldk + (long)kvh * HD + ks * 16 + fq * 4);
-    vf[ks] = *reinterpret_cast<const s16x4*>(V + krow * ldk + (long)kvh * HD + ks * 16 + fq * 4);
-  }
-  f32x4 accK[NKS], accV[NKS];
+    for (int j = 0; j < 4; ++j) {
+      const int pi = wave * 4 + j;
+      int key = st * 64 + pi * 4 + (lane >> 4);
+      const int sc = (lane & 15) ^ (((lane >> 4) << 2) | j);
+      key = key < kend - 1 ? key : kend - 1;
+      const bool inA = key < w.ka_len;
+      const long off = (long)(inA ? w.ka_row0 + key : w.kb_row0 + key - w.ka_len) * ldk + kvh * HD + sc * 8;
+      vr2_dma16((inA ? KA : KB) + off, stg + pi * 1024);
+      vr2_dma16((inA ? VA : VB) + off, stg + TILE_B + pi * 1024);
+    }
+  };
+  auto compute = [&](int st, auto masked_tag) {
+    constexpr bool MASK = decltype(masked_tag)::value;
+    const char* sK = smem + (st % DQ_NSTAGE) * DQ_STAGE_B;
+    const char* sV = sK + TILE_B;
 #pragma unroll
-  for (int i = 0; i < NKS; ++i) { accK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int range = 0; range < 2; ++range) {
-    const int r0 = range == 0 ? w.q1_row0 : w.q2_row0;
-    const int rl = range == 0 ? w.q1_len : w.q2_len;
-    const bool causal = range == 0;
-    for (int hq = 0; hq < group; ++hq) {
-      const int head = kvh * group + hq;
-      for (int q0 = 0; q0 < rl; q0 += KT) {
-        __syncthreads();
-        for (int c = threadIdx.x; c < KT * 16; c += 256) {
-          const int qr = c >> 4, ch = c & 15;
-          bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, dv = qv;
-          if (q0 + qr < rl) {
-            const long off = (long)(r0 + q0 + qr) * ldq + (long)head * HD + ch * 8;
-            qv = *reinterpret_cast<const bf16x8*>(Q + off);
-            dv = *reinterpret_cast<const bf16x8*>(dO + off);
+    for (int h = 0; h < 2; ++h) {
+      f32x4 sa[2][2], da[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { sa[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; da[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const bf16x8 ak = row_frag(sK, h, b, ks, lane), av = row_frag(sV, h, b, ks, lane);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            sa[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, qf[s][ks], sa[b][s], 0, 0, 0);
+            da[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, df[s][ks], da[b][s], 0, 0, 0);
           }
-          *reinterpret_cast<bf16x8*>(sQ + qr * STR_T + ch * 8) = qv;
-          *reinterpret_cast<bf16x8*>(sD + qr * STR_T + ch * 8) = dv;
         }
-        if (threadIdx.x < KT) {
-          const bool ok = q0 + (int)threadIdx.x < rl;
-          const long idx = (long)(r0 + q0 + (ok ? (int)threadIdx.x : 0)) * n_heads + head;
-          sL[threadIdx.x] = ok ? LSE[idx] : INFINITY;   // +inf -> p = 0 for rows past the range
-          sDl[threadIdx.x] = ok ? DELTA[idx] : 0.f;
-        }
-        __syncthreads();
-        s16x4 pb[4], dsb[4];
+      // lane: query slot fr of both query sets (column), keys 64 st + 32 h + 8 fq + 4 b + r
+      bf16x8 dsb[2];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          const bf16* qp = sQ + (b * 16 + fr) * STR_T + fq * 4;
-          const bf16* dp_ = sD + (b * 16 + fr) * STR_T + fq * 4;
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(qp + ks * 16), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(dp_ + ks * 16), vf[ks], dp, 0, 0, 0);
-          }
-          // lane: key slot fr (column), query rows 16b + 4fq + r
-          bf16x4 p4, d4;
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int ql = b * 16 + fq * 4 + r;
-            const long qabs = (long)r0 + q0 + ql;
-            const bool ok = kvalid && (q0 + ql < rl) && (!causal || krow <= qabs);
-            const float p = ok ? __expf(s[r] * scale - sL[ql]) : 0.f;
-            p4[r] = f2bf(p);
-            d4[r] = f2bf(p * (dp[r] - sDl[ql]) * scale);
+            float p = __builtin_amdgcn_exp2f(c2 * sa[b][s][r] + nls[s]);
+            if (MASK) p = (st * 64 + 32 * h + 8 * fq + 4 * b + r) < vis_lim[s] ? p : 0.f;
+            dsb[s][4 * b + r] = f2bf(p * (da[b][s][r] - dl[s]));
           }
-          pb[b] = __builtin_bit_cast(s16x4, p4);
-          dsb[b] = __builtin_bit_cast(s16x4, d4);
-        }
 #pragma unroll
-        for (int db = 0; db < NKS; ++db) {
-          f32x4 ok_ = accK[db], ov = accV[db];
+      for (int db = 0; db < 8; ++db) {
+        const bf16x8 ak = tr_frag(sK, h, db, lane);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int off = (b * 16 + fq * 4 + (fr >> 2)) * STR_T + db * 16 + (fr & 3) * 4;
-            ov = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tr_read(sD + off), pb[b], ov, 0, 0, 0);
-            ok_ = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tr_read(sQ + off), dsb[b], ok_, 0, 0, 0);
-          }
-          accK[db] = ok_;
-          accV[db] = ov;
-        }
+        for (int s = 0; s < 2; ++s) acc[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, dsb[s], acc[s][db], 0, 0, 0);
       }
     }
+  };
+
+  if (nsteps > 0) issue(0);
+  for (int st = 0; st < nsteps; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (st + 1 < nsteps) issue(st + 1);
+    if (st * 64 + 64 > min_lim) compute(st, std::true_type{});
+    else compute(st, std::false_type{});
   }
-  if (!kvalid) return;
-  float* ok = dK + krow * ldk + (long)kvh * HD + fq * 4;
-  float* ov = dV + krow * ldk + (long)kvh * HD + fq * 4;
+  // epilogue: the wave's 32 query rows go through LDS and leave as whole 256-byte bf16 rows
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float* stg = reinterpret_cast<float*>(smem) + wave * 32 * OUT_STRIDE;
 #pragma unroll
-  for (int db = 0; db < NKS; ++db)
+  for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      atomicAdd(ok + db * 16 + r, accK[db][r]);
-      atomicAdd(ov + db * 16 + r, accV[db][r]);
+    for (int db = 0; db < 8; ++db) {
+      f32x4 v = acc[s][db];
+      v[0] *= scale; v[1] *= scale; v[2] *= scale; v[3] *= scale;
+      *reinterpret_cast<f32x4*>(stg + (s * 16 + fr) * OUT_STRIDE + db * 16 + 4 * fq) = v;
     }
+  const int nrows = (w.nq - wave * 32) < 32 ? (w.nq - wave * 32) : 32;
+  bf16* dst = dQ + (long)(w.q_row0 + wave * 32) * ldq + (long)head * HD;
+  for (int rr = 0; rr < nrows; ++rr) {
+    const float2 v = *reinterpret_cast<const float2*>(stg + rr * OUT_STRIDE + 2 * lane);
+    bf16x2 o = {f2bf(v.x), f2bf(v.y)};
+    *reinterpret_cast<bf16x2*>(dst + (long)rr * ldq + 2 * lane) = o;
+  }
 }
 
 }  // namespace
@@ -239,34 +374,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const KeyWork* __rest
 #define STREAM ((hipStream_t)stream)
 
 extern "C" int vr2_attn_delta(const void* O_bf16, const void* dO_bf16, int64_t ld, int64_t T, int64_t n_heads, int64_t head_dim,
-                              void* delta_f32, void* stream) {
+                              const void* lse_f32, void* rowc_f32, void* stream) {
   VR2_REQUIRE(head_dim == 128 && T >= 1, "vr2_attn_delta: head_dim 128 only");
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)T), dim3(256), 0, STREAM, (const bf16*)O_bf16, (const bf16*)dO_bf16, (long)ld,
-                     (int)n_heads, (float*)delta_f32);
+                     (int)n_heads, (const float*)lse_f32, (float*)rowc_f32, (long)T);
   return vr2_check_launch("vr2_attn_delta");
 }
 
 extern "C" int vr2_attn_bwd_dq(const void* work_i32x8, int64_t n_work, const void* Q, int64_t ldq, const void* KA, const void* VA,
-                               const void* KB, const void* VB, int64_t ldk, const void* dO, const void* lse_f32,
-                               const void* delta_f32, void* dQ, int64_t n_heads, int64_t group, int64_t head_dim, float scale,
-                               void* stream) {
+                               const void* KB, const void* VB, int64_t ldk, const void* dO, const void* rowc_f32, int64_t T,
+                               void* dQ, int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* stream) {
   VR2_REQUIRE(head_dim == 128, "vr2_attn_bwd_dq: head_dim 128 only (the LM; the ViT is frozen)");
-  VR2_REQUIRE(n_work >= 1 && n_heads % group == 0 && ldq % 4 == 0 && ldk % 8 == 0, "vr2_attn_bwd_dq: bad arguments");
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_work, (unsigned)n_heads), dim3(256), 0, STREAM, (const AttnWork*)work_i32x8,
-                     (const bf16*)Q, (long)ldq, (const bf16*)KA, (const bf16*)VA, (const bf16*)KB, (const bf16*)VB, (long)ldk,
-                     (const bf16*)dO, (const float*)lse_f32, (const float*)delta_f32, (bf16*)dQ, (int)n_heads, (int)group, scale);
+  VR2_REQUIRE(n_work >= 1 && n_heads % group == 0 && ldq % 8 == 0 && ldk % 8 == 0, "vr2_attn_bwd_dq: bad arguments");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * OUT_STRIDE * 4);
+    attr = true;
+  }
+  static_assert(4 * 32 * OUT_STRIDE * 4 >= DQ_NSTAGE * DQ_STAGE_B, "dq: the output staging region is the larger one");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_work, (unsigned)n_heads), dim3(256), 4 * 32 * OUT_STRIDE * 4, STREAM,
+                     (const AttnWork*)work_i32x8, (const bf16*)Q, (long)ldq, (const bf16*)KA, (const bf16*)VA, (const bf16*)KB,
+                     (const bf16*)VB, (long)ldk, (const bf16*)dO, (const float*)rowc_f32, (long)T, (bf16*)dQ, (int)n_heads,
+                     (int)group, scale);
   return vr2_check_launch("vr2_attn_bwd_dq");
 }
 
 extern "C" int vr2_attn_bwd_dkv(const void* keywork_i32x8, int64_t n_work, const void* Q, int64_t ldq, const void* K, const void* V,
-                                int64_t ldk, const void* dO, const void* lse_f32, const void* delta_f32, void* dK_f32,
-                                void* dV_f32, int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* stream) {
+                                int64_t ldk, const void* dO, const void* rowc_f32, int64_t T, void* dK_f32, void* dV_f32,
+                                int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* stream) {
   void* dK = dK_f32; void* dV = dV_f32;   // fp32 [T][ldk], ZEROED by the caller: work items add into them
   VR2_REQUIRE(head_dim == 128, "vr2_attn_bwd_dkv: head_dim 128 only (the LM; the ViT is frozen)");
-  VR2_REQUIRE(n_work >= 1 && n_heads % group == 0 && ldq % 8 == 0 && ldk % 4 == 0, "vr2_attn_bwd_dkv: bad arguments");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_work, (unsigned)(n_heads / group)), dim3(256), 0, STREAM,
+  VR2_REQUIRE(n_work >= 1 && n_heads % group == 0 && ldq % 8 == 0 && ldk % 8 == 0, "vr2_attn_bwd_dkv: bad arguments");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_NSTAGE * KV_STAGE_B);
+    attr = true;
+  }
+  static_assert(KV_NSTAGE * KV_STAGE_B >= 4 * 32 * OUT_STRIDE * 4, "dkv: the ring holds the output staging region");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_work, (unsigned)(n_heads / group)), dim3(256), KV_NSTAGE * KV_STAGE_B, STREAM,
                      (const KeyWork*)keywork_i32x8, (const bf16*)Q, (long)ldq, (const bf16*)K, (const bf16*)V, (long)ldk,
-                     (const bf16*)dO, (const float*)lse_f32, (const float*)delta_f32, (float*)dK, (float*)dV, (int)n_heads,
-                     (int)group, scale);
+                     (const bf16*)dO, (const float*)rowc_f32, (long)T, (float*)dK, (float*)dV, (int)n_heads, (int)group, scale);
   return vr2_check_launch("vr2_attn_bwd_dkv");
 }

@@ -63,5 +63,17 @@ __device__ __forceinline__ float block_max_256(float v, float* scratch) {
   return fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
 }
 
+// Direct-to-LDS loads as inline asm: hipcc's wait-count pass treats the builtin form as an LDS store that every later LDS read
+// may alias and puts s_waitcnt vmcnt(0) in front of each ds_read_b64_tr_b16, which would drain the ring at every tile.  Written
+// this way the pass does not see them; the kernels wait for them by count (vmcnt) in front of the tile's barrier.
+__device__ __forceinline__ void vr2_dma16(const void* g, const void* l) {
+  const unsigned la = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)l;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
+__device__ __forceinline__ void vr2_dma4(const void* g, const void* l) {
+  const unsigned la = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)l;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

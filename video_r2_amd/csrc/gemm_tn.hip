@@ -156,9 +156,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const bf16* __restrict_
       ga[h][i] = A + (long)(4 * piece + ar) * lda + ca;
       gb[h][i] = B + (long)(4 * piece + ar) * ldb + cb;
     }
-  auto glds = [](const bf16* g, char* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-  };
+  auto glds = [](const bf16* g, char* l) { vr2_dma16(g, l); };   // asm form: no compiler vmcnt(0) in front of the transposed reads
   auto stage_a = [&](int h, int T) {
     if (T >= NT) return;
     char* dst = smem + (T & 1) * 65536 + h * 16384 + wave * 2048;
@@ -229,21 +227,27 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const bf16* __restrict_
   }
 #undef VR2_MMA
   if (wm == 0) __builtin_amdgcn_s_barrier();
+  // (+)= epilogue: the 8 reads of a column group are issued together, then added and stored (one read-wait-store at a time left
+  // the workgroup's 512 KiB of fp32 read-modify-write latency-bound)
 #pragma unroll
   for (int in = 0; in < 4; ++in) {
     const int n = n0 + wn * 64 + in * 16 + fq * 4;
-    if (n >= N) continue;
+    const bool nok = n < N;
+    float4 o[8];
+    float* cp[8];
+    bool ok[8];
 #pragma unroll
     for (int im = 0; im < 8; ++im) {
       const int m = m0 + wm * 128 + im * 16 + fr;
-      if (m >= M) continue;
-      float* cp = C + (long)m * ldc + n;
+      ok[im] = nok && m < M;
+      cp[im] = C + (long)(ok[im] ? m : 0) * ldc + (nok ? n : 0);
+      if (ACC) o[im] = ok[im] ? *reinterpret_cast<const float4*>(cp[im]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int im = 0; im < 8; ++im) {
       float4 v = make_float4(acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]);
-      if (ACC) {
-        const float4 o = *reinterpret_cast<const float4*>(cp);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
-      *reinterpret_cast<float4*>(cp) = v;
+      if (ACC) { v.x += o[im].x; v.y += o[im].y; v.z += o[im].z; v.w += o[im].w; }
+      if (ok[im]) *reinterpret_cast<float4*>(cp[im]) = v;
     }
   }
 }

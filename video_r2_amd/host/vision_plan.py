@@ -79,25 +79,40 @@ def causal_work(n_q, q_row0, prefix_row0, prefix_len, self_row0, q_tile=Q_TILE, 
     return np.asarray(items, dtype=np.int32).reshape(-1, 8)
 
 
-def key_work(n_prompt, n_seq, n_comp, k_tile=Q_TILE, q_split=1024):
+def key_work(n_prompt, n_seq, n_comp, k_tile=128, q_split=512, group=1, max_steps=64):
     """Key-centric work items (vr2_attn_bwd_dkv) for the unified row space [prompt rows | seq 0 rows | seq 1 rows | ...]:
-    a prompt key tile is seen by the prompt rows from its first row on (causal) and by EVERY completion row; a completion key
-    tile by the later rows of its own sequence (causal).  The all-visible range (n_seq * n_comp rows) is cut into q_split-row
-    pieces so no workgroup walks more than ~q_split rows; the pieces add into the same fp32 dK/dV rows.
-    int32 [n,8]: k_row0, nk, q1_row0, q1_len, q2_row0, q2_len, 0, 0."""
+    a prompt key tile (k_tile <= 128 rows) is seen by the prompt rows from its first row on (causal) and by EVERY completion
+    row; a completion key tile by the later rows of its own sequence (causal).  The all-visible range (n_seq * n_comp rows) is
+    cut into q_split-row pieces, and an item that would still walk more than max_steps (q head, 64-row query tile) steps is cut
+    again by q heads of the GQA group (`group` heads per KV head), so that no workgroup runs much longer than the others; the
+    pieces add into the same fp32 dK/dV rows.  Heaviest items first (the grid is dispatched in order).
+    int32 [n,8]: k_row0, nk, q1_row0, q1_len, q2_row0, q2_len, head0, nheads."""
+    assert 1 <= k_tile <= 128
     items = []
+
+    def add(k0, nk, q1r, q1l, q2r, q2l):
+        tiles = (q1l + 63) // 64 + (q2l + 63) // 64
+        parts = min(group, max(1, -(-(tiles * group) // max_steps)))
+        base, extra = divmod(group, parts)
+        h0 = 0
+        for i in range(parts):
+            nh = base + (1 if i < extra else 0)
+            items.append((tiles * nh, (k0, nk, q1r, q1l, q2r, q2l, h0, nh)))
+            h0 += nh
+
     total_c = n_seq * n_comp
     for k0 in range(0, n_prompt, k_tile):
         nk = min(k_tile, n_prompt - k0)
-        items.append((k0, nk, k0, n_prompt - k0, 0, 0, 0, 0))
+        add(k0, nk, k0, n_prompt - k0, 0, 0)
         for c0 in range(0, total_c, q_split):
-            items.append((k0, nk, 0, 0, n_prompt + c0, min(q_split, total_c - c0), 0, 0))
+            add(k0, nk, 0, 0, n_prompt + c0, min(q_split, total_c - c0))
     for g in range(n_seq):
         base = n_prompt + g * n_comp
         for k0 in range(0, n_comp, k_tile):
             nk = min(k_tile, n_comp - k0)
-            items.append((base + k0, nk, base + k0, n_comp - k0, 0, 0, 0, 0))
-    return np.asarray(items, dtype=np.int32).reshape(-1, 8)
+            add(base + k0, nk, base + k0, n_comp - k0, 0, 0)
+    items.sort(key=lambda it: -it[0])
+    return np.asarray([it[1] for it in items], dtype=np.int32).reshape(-1, 8)
 
 
 @dataclass

@@ -151,6 +151,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const KeyWork* __rest
     const char* sQ = smem + (st % KV_NSTAGE) * KV_STAGE_B;
     const char* sD = sQ + TILE_B;
     const float* sR = reinterpret_cast<const float*>(sQ + 2 * TILE_B);
+    // fragment reads run ahead of the MFMAs that use them (one wave per SIMD: nothing else hides the LDS latency): row
+    // fragments one k-step (8 MFMAs) ahead, transposed fragments two feature blocks (8 MFMAs) ahead
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       f32x4 sa[2][2], da[2][2];
@@ -158,17 +160,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const KeyWork* __rest
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int s = 0; s < 2; ++s) { sa[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; da[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      bf16x8 fq_[2][2], fd_[2][2];   // [ring][b]
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int b = 0; b < 2; ++b) { fq_[0][b] = row_frag(sQ, h, b, 0, lane); fd_[0][b] = row_frag(sD, h, b, 0, lane); }
+      bf16x8 tq[3], td[3];           // transposed fragments, ring of 3
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const bf16x8 aq = row_frag(sQ, h, b, ks, lane), ad = row_frag(sD, h, b, ks, lane);
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) { fq_[(ks + 1) & 1][b] = row_frag(sQ, h, b, ks + 1, lane); fd_[(ks + 1) & 1][b] = row_frag(sD, h, b, ks + 1, lane); }
+        } else {
+          td[0] = tr_frag(sD, h, 0, lane); tq[0] = tr_frag(sQ, h, 0, lane);
+          td[1] = tr_frag(sD, h, 1, lane); tq[1] = tr_frag(sQ, h, 1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads in front of the MFMAs (the scheduler would sink them to their uses)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            sa[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, kf[s][ks], sa[b][s], 0, 0, 0);
-            da[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, vf[s][ks], da[b][s], 0, 0, 0);
+            sa[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq_[ks & 1][b], kf[s][ks], sa[b][s], 0, 0, 0);
+            da[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd_[ks & 1][b], vf[s][ks], da[b][s], 0, 0, 0);
           }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // lane: key slot fr of both key sets (column), tile rows 32 h + 8 fq + 4 b + r
       bf16x8 pb[2], dsb[2];
 #pragma unroll
@@ -192,12 +206,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const KeyWork* __rest
       }
 #pragma unroll
       for (int db = 0; db < 8; ++db) {
-        const bf16x8 ad = tr_frag(sD, h, db, lane), aq = tr_frag(sQ, h, db, lane);
+        if (db + 2 < 8) { td[(db + 2) % 3] = tr_frag(sD, h, db + 2, lane); tq[(db + 2) % 3] = tr_frag(sQ, h, db + 2, lane); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          accV[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, pb[s], accV[s][db], 0, 0, 0);
-          accK[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, dsb[s], accK[s][db], 0, 0, 0);
+          accV[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(td[db % 3], pb[s], accV[s][db], 0, 0, 0);
+          accK[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq[db % 3], dsb[s], accK[s][db], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -310,17 +326,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnWork* __rest
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int s = 0; s < 2; ++s) { sa[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; da[b][s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      bf16x8 fk[2][2], fv[2][2];   // [ring][b]: row fragments one k-step ahead of their MFMAs
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int b = 0; b < 2; ++b) { fk[0][b] = row_frag(sK, h, b, 0, lane); fv[0][b] = row_frag(sV, h, b, 0, lane); }
+      bf16x8 tk[4];                // transposed fragments, ring of 4: three feature blocks (6 MFMAs) ahead
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const bf16x8 ak = row_frag(sK, h, b, ks, lane), av = row_frag(sV, h, b, ks, lane);
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) { fk[(ks + 1) & 1][b] = row_frag(sK, h, b, ks + 1, lane); fv[(ks + 1) & 1][b] = row_frag(sV, h, b, ks + 1, lane); }
+        } else {
+          tk[0] = tr_frag(sK, h, 0, lane); tk[1] = tr_frag(sK, h, 1, lane); tk[2] = tr_frag(sK, h, 2, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads in front of the MFMAs (the scheduler would sink them to their uses)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            sa[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, qf[s][ks], sa[b][s], 0, 0, 0);
-            da[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, df[s][ks], da[b][s], 0, 0, 0);
+            sa[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[ks & 1][b], qf[s][ks], sa[b][s], 0, 0, 0);
+            da[b][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[ks & 1][b], df[s][ks], da[b][s], 0, 0, 0);
           }
-        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // lane: query slot fr of both query sets (column), keys 64 st + 32 h + 8 fq + 4 b + r
       bf16x8 dsb[2];
 #pragma unroll
@@ -335,9 +362,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnWork* __rest
           }
 #pragma unroll
       for (int db = 0; db < 8; ++db) {
-        const bf16x8 ak = tr_frag(sK, h, db, lane);
+        if (db + 3 < 8) tk[(db + 3) & 3] = tr_frag(sK, h, db + 3, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, dsb[s], acc[s][db], 0, 0, 0);
+        for (int s = 0; s < 2; ++s) acc[s][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tk[db & 3], dsb[s], acc[s][db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };

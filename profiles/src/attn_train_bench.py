@@ -36,7 +36,7 @@ def timeit(name, fn, flops, n=10):
     ms = e0.elapsed_time(e1) / n
     print(f"{name:34s} {ms*1e3:9.1f} us   {flops/ms/1e9:8.1f} TFLOP/s", flush=True)
 
-timeit("attn_tok fwd (+lse)", lambda: lib.call("vr2_attn_tok", dwork, dwork.shape[0], q, nH * hd, k, v, k, v, nKV * hd, o, nH * hd, nH, group, hd, scale, lse, st), fl)
+timeit("attn_tok fwd (+lse)", lambda: lib.call("vr2_attn_tok", dwq, dwq.shape[0], q, nH * hd, k, v, k, v, nKV * hd, o, nH * hd, nH, group, hd, scale, lse, st), fl)
 timeit("attn_delta", lambda: lib.call("vr2_attn_delta", o, do, nH * hd, T, nH, hd, lse, rowc, st), 0)
 timeit("attn_bwd_dq", lambda: lib.call("vr2_attn_bwd_dq", dwq, dwq.shape[0], q, nH * hd, k, v, k, v, nKV * hd, do, rowc, T, dq, nH, group, hd, scale, st), fl * 1.5)
 for qs, ms_ in ((512, 64), (1024, 64), (512, 32), (1024, 128)):

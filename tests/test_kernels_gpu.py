@@ -256,7 +256,8 @@ def test_attn_tok_varlen_and_causal(dev, hd):
     Sp, C, G = 100, 70, 2
     kp = bf(torch.randn(Sp, nKV, hd, generator=g)); vpp = bf(torch.randn(Sp, nKV, hd, generator=g))
     q = bf(torch.randn(G * C, nH, hd, generator=g)); k = bf(torch.randn(G * C, nKV, hd, generator=g)); v = bf(torch.randn(G * C, nKV, hd, generator=g))
-    work = torch.from_numpy(np.concatenate([vp.causal_work(C, gg * C, 0, Sp, gg * C) for gg in range(G)])).to(dev)
+    qt = vp.LM_Q_TILE if hd == 128 else vp.Q_TILE
+    work = torch.from_numpy(np.concatenate([vp.causal_work(C, gg * C, 0, Sp, gg * C, q_tile=qt) for gg in range(G)])).to(dev)
     o = torch.zeros(G * C, nH * hd, dtype=torch.bfloat16, device=dev)
     lib.call("vr2_attn_tok", work, work.shape[0], q.reshape(G * C, -1).to(dev), nH * hd, kp.reshape(Sp, -1).to(dev),
              vpp.reshape(Sp, -1).to(dev), k.reshape(G * C, -1).to(dev), v.reshape(G * C, -1).to(dev), nKV * hd, o, nH * hd,

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvr2.so")
-SOURCES = ["api.hip", "gemv.hip", "gemv_w8.hip", "gemm.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "attention_bwd.hip",
+SOURCES = ["api.hip", "gemv.hip", "gemv_w8.hip", "gemm.hip", "gemm_tn.hip", "elementwise.hip", "attention.hip", "attention_fwd.hip", "attention_bwd.hip",
            "sample.hip", "backward.hip", "optim.hip"]
 
 

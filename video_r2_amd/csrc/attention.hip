@@ -416,12 +416,11 @@ extern "C" int vr2_attn_tok(const void* work_i32x8, int64_t n_work, const void* 
   VR2_REQUIRE(ldq % 4 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "vr2_attn_tok: strides must keep 8/16-byte alignment");
   dim3 grid((unsigned)n_work, (unsigned)n_heads);
   hipStream_t s = (hipStream_t)stream;
-  if (head_dim == 128)
-    hipLaunchKernelGGL(attn_tok_kernel<128>, grid, dim3(256), 0, s, (const AttnWork*)work_i32x8, (const bf16*)Q, (long)ldq,
-                       (const bf16*)KA, (const bf16*)VA, (const bf16*)KB, (const bf16*)VB, (long)ldk, (bf16*)O, (long)ldo,
-                       (int)group, scale, (float*)lse_out_f32, (int)n_heads);
-  else
-    hipLaunchKernelGGL(attn_tok_kernel<80>, grid, dim3(256), 0, s, (const AttnWork*)work_i32x8, (const bf16*)Q, (long)ldq,
+  if (head_dim == 128) {   // the LM: 128 query rows per workgroup (attention_fwd.hip)
+    VR2_REQUIRE(ldq % 8 == 0, "vr2_attn_tok: head_dim 128 needs ldq %% 8 == 0");
+    return vr2_launch_attn_fwd128(work_i32x8, n_work, Q, ldq, KA, VA, KB, VB, ldk, O, ldo, n_heads, group, scale, lse_out_f32, stream);
+  }
+  hipLaunchKernelGGL(attn_tok_kernel<80>, grid, dim3(256), 0, s, (const AttnWork*)work_i32x8, (const bf16*)Q, (long)ldq,
                        (const bf16*)KA, (const bf16*)VA, (const bf16*)KB, (const bf16*)VB, (long)ldk, (bf16*)O, (long)ldo,
                        (int)group, scale, (float*)lse_out_f32, (int)n_heads);
   return vr2_check_launch("vr2_attn_tok");

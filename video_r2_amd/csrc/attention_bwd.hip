@@ -21,41 +21,11 @@
 // the accumulators of blocks 0 and 1 then hold, per lane, 8 CONSECUTIVE rows 8 (lane >> 4) .. + 7 of the half, which is exactly
 // the k order the next MFMA's B operand wants, so P and dS feed it from registers.
 #include <type_traits>
-#include "common.h"
+#include "attn_tile.h"
 
 namespace {
 
-struct AttnWork { int q_row0, nq, ka_row0, ka_len, kb_row0, kb_len, q_causal0, pad; };
 struct KeyWork { int k_row0, nk, q1_row0, q1_len, q2_row0, q2_len, head0, nheads; };  // q1: causal (key row <= query row); q2: all visible
-
-constexpr int HD = 128;
-constexpr int TILE_B = 64 * 256;                 // one swept tile: 64 rows x 256 B
-constexpr int ROWC_B = 512;                      // dkv: 4 waves x [16 x -lse*log2e | 16 x delta] fp32
-constexpr int KV_STAGE_B = 2 * TILE_B + ROWC_B;  // dkv ring stage: Q tile | dO tile | row constants
-constexpr int KV_NSTAGE = 3;
-constexpr int DQ_STAGE_B = 2 * TILE_B;           // dq ring stage: K tile | V tile
-constexpr int DQ_NSTAGE = 2;
-constexpr int OUT_STRIDE = 132;                  // fp32 words per staged output row (528 B: conflict-free 16-byte writes)
-constexpr float LOG2E = 1.4426950408889634f;
-
-__device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
-
-// A operand read by rows: MFMA row i = tile row 32 h + (i & 3) + 8 (i >> 2) + 4 b, k = features 32 ks + 8 fq .. + 7
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int h, int b, int ks, int lane) {
-  const int i = lane & 15, fq = lane >> 4;
-  const int row = 32 * h + (i & 3) + 8 * (i >> 2) + 4 * b;
-  return *reinterpret_cast<const bf16x8*>(tile + img_off(row, ks * 4 + fq));
-}
-// A operand read transposed: MFMA row i = feature 16 db + i, k = tile rows 32 h + 8 fq .. + 7 (two 4-row blocks)
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int h, int db, int lane) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 vb4;
-  const int fq = lane >> 4, a = (lane & 15) >> 2, p = lane & 3;
-  const int row = 32 * h + 8 * fq + a, ch = db * 2 + (p >> 1);
-  const vb4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) vb4*)(tile + img_off(row, ch) + 8 * (p & 1)));
-  const vb4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) vb4*)(tile + img_off(row + 4, ch) + 8 * (p & 1)));
-  bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return r;
-}
 
 // delta[t][h] = sum_d dO[t][h][d] * O[t][h][d];  rowc[0][h][t] = -lse[t][h] * log2(e), rowc[1][h][t] = delta
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, long ld, int n_heads,
@@ -380,22 +350,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnWork* __rest
   }
   // epilogue: the wave's 32 query rows go through LDS and leave as whole 256-byte bf16 rows
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  float* stg = reinterpret_cast<float*>(smem) + wave * 32 * OUT_STRIDE;
+  bf16* stg = reinterpret_cast<bf16*>(smem) + wave * 32 * OUT_STRIDE_BF;
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int db = 0; db < 8; ++db) {
-      f32x4 v = acc[s][db];
-      v[0] *= scale; v[1] *= scale; v[2] *= scale; v[3] *= scale;
-      *reinterpret_cast<f32x4*>(stg + (s * 16 + fr) * OUT_STRIDE + db * 16 + 4 * fq) = v;
+      const f32x4 v = acc[s][db];
+      bf16x4 o = {f2bf(v[0] * scale), f2bf(v[1] * scale), f2bf(v[2] * scale), f2bf(v[3] * scale)};
+      *reinterpret_cast<bf16x4*>(stg + (s * 16 + fr) * OUT_STRIDE_BF + db * 16 + 4 * fq) = o;
     }
-  const int nrows = (w.nq - wave * 32) < 32 ? (w.nq - wave * 32) : 32;
-  bf16* dst = dQ + (long)(w.q_row0 + wave * 32) * ldq + (long)head * HD;
-  for (int rr = 0; rr < nrows; ++rr) {
-    const float2 v = *reinterpret_cast<const float2*>(stg + rr * OUT_STRIDE + 2 * lane);
-    bf16x2 o = {f2bf(v.x), f2bf(v.y)};
-    *reinterpret_cast<bf16x2*>(dst + (long)rr * ldq + 2 * lane) = o;
-  }
+  store_rows_bf16(stg, dQ + (long)(w.q_row0 + wave * 32) * ldq + (long)head * HD, ldq, w.nq - wave * 32, lane);
 }
 
 }  // namespace
@@ -417,11 +381,11 @@ extern "C" int vr2_attn_bwd_dq(const void* work_i32x8, int64_t n_work, const voi
   VR2_REQUIRE(n_work >= 1 && n_heads % group == 0 && ldq % 8 == 0 && ldk % 8 == 0, "vr2_attn_bwd_dq: bad arguments");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * OUT_STRIDE * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_NSTAGE * DQ_STAGE_B);
     attr = true;
   }
-  static_assert(4 * 32 * OUT_STRIDE * 4 >= DQ_NSTAGE * DQ_STAGE_B, "dq: the output staging region is the larger one");
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_work, (unsigned)n_heads), dim3(256), 4 * 32 * OUT_STRIDE * 4, STREAM,
+  static_assert(DQ_NSTAGE * DQ_STAGE_B >= 4 * 32 * OUT_STRIDE_BF * 2, "dq: the ring holds the output staging region");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_work, (unsigned)n_heads), dim3(256), DQ_NSTAGE * DQ_STAGE_B, STREAM,
                      (const AttnWork*)work_i32x8, (const bf16*)Q, (long)ldq, (const bf16*)KA, (const bf16*)VA, (const bf16*)KB,
                      (const bf16*)VB, (long)ldk, (const bf16*)dO, (const float*)rowc_f32, (long)T, (bf16*)dQ, (int)n_heads,
                      (int)group, scale);

@@ -23,6 +23,11 @@ int vr2_check_launch(const char* what);
 enum { VR2_TUNE_GEMV_VARIANT = 0, VR2_TUNE_GEMV_ABLATE = 1, VR2_TUNE_GEMV_XCHUNK = 2, VR2_TUNE_COUNT = 8 };
 int vr2_tune_get(int key);
 
+// attention_fwd.hip: the head_dim-128 forward behind vr2_attn_tok
+int vr2_launch_attn_fwd128(const void* work_i32x8, int64_t n_work, const void* Q, int64_t ldq, const void* KA, const void* VA,
+                           const void* KB, const void* VB, int64_t ldk, void* O, int64_t ldo, int64_t n_heads, int64_t group,
+                           float scale, void* lse_out, void* stream);
+
 #define VR2_REQUIRE(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

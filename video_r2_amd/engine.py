@@ -450,7 +450,7 @@ class Engine:
         else:
             pk = self.buf(tag + ".prefix_k", (t.num_hidden_layers, S, nkv * hd), torch.bfloat16)
             pv = self.buf(tag + ".prefix_v", (t.num_hidden_layers, S, nkv * hd), torch.bfloat16)
-        work = _i32(vp.causal_work(S, 0, 0, 0, 0), self.device)
+        work = _i32(vp.causal_work(S, 0, 0, 0, 0, q_tile=vp.LM_Q_TILE), self.device)
         self._lm_rows(W, x, S, cos, sin, work, None, None, pk, pv, 0, tag + ".p")
         slot = "" if prefix_out is None else str(pk.data_ptr())
         last = self.buf(tag + ".plast" + slot, (1, H), torch.float32)
@@ -501,7 +501,7 @@ class Engine:
             pos_all[:, p_, :S] = pos
             deltas.append(delta)
             # queries = this prompt's rows of the batch; keys = its own cache slot, causal (row index relative to slot 0 of the layer)
-            works.append(vp.causal_work(S, p_ * rp, 0, 0, p_ * gstride))
+            works.append(vp.causal_work(S, p_ * rp, 0, 0, p_ * gstride, q_tile=vp.LM_Q_TILE))
         x = self.buf(tag + ".bx", (T, H), torch.float32)
         d_ids = _i32(ids_all.reshape(-1), self.device)
         lib.call("vr2_embed_rows", d_ids, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, self.s)
@@ -767,7 +767,7 @@ class Engine:
         lib.call("vr2_mrope_table", d_pos, T, self.inv_freq, self.section, cos, sin, hd, self.s)
         ks = self.buf(tag + ".sk", (T, nkv * hd), torch.bfloat16)
         vs = self.buf(tag + ".sv", (T, nkv * hd), torch.bfloat16)
-        work = np.concatenate([vp.causal_work(C, g * C, 0, S, g * C) for g in range(G)], 0)
+        work = np.concatenate([vp.causal_work(C, g * C, 0, S, g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0)
         d_work = _i32(work, self.device)
         self._lm_rows(W, x, T, cos, sin, d_work, st.prefix_k, st.prefix_v, ks, vs, 0, tag + ".s")
         # shift: hs[(g,0)] = prompt last hidden ; hs[(g,j)] = x[(g,j-1)]

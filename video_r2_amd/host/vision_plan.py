@@ -11,7 +11,8 @@ from dataclasses import dataclass
 
 import numpy as np
 
-Q_TILE = 64  # query rows per attention workgroup (4 waves x 16 slots)
+Q_TILE = 64  # query rows per attention workgroup, head_dim 80 (the ViT: 4 waves x 16 slots)
+LM_Q_TILE = 128  # head_dim 128 (the LM forward and dQ kernels: 4 waves x 32 rows)
 
 
 def window_index(grid_thw, merge_size=2, window_size=112, patch_size=14):

@@ -165,11 +165,10 @@ class Trainer:
             lib.call("vr2_scatter_rows_f32", video_embeds, video_embeds.stride(0), dst, x, x.stride(0), vid_pos.shape[0], H, eng.s)
         cos = b("t.cos", (T, hd // 2), torch.float32); sin = b("t.sin", (T, hd // 2), torch.float32)
         lib.call("vr2_mrope_table", _i32(pos_all, eng.device), T, eng.inv_freq, eng.section, cos, sin, hd, eng.s)
-        work = np.concatenate([vp.causal_work(S, 0, 0, 0, 0)] + [vp.causal_work(C, S + g * C, 0, S, S + g * C) for g in range(G)], 0)
+        work = np.concatenate([vp.causal_work(S, 0, 0, 0, 0, q_tile=vp.LM_Q_TILE)] +
+                              [vp.causal_work(C, S + g * C, 0, S, S + g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0)
         d_work = _i32(work, eng.device)
         kwork = _i32(vp.key_work(S, G, C, group=t.group), eng.device)
-        work_dq = _i32(np.concatenate([vp.causal_work(S, 0, 0, 0, 0, q_tile=128)] +
-                                      [vp.causal_work(C, S + g * C, 0, S, S + g * C, q_tile=128) for g in range(G)], 0), eng.device)
         sv = dict(x_in=b("t.x_in", (L, T, H), torch.float32), xn1=b("t.xn1", (L, T, H), torch.bfloat16),
                   q=b("t.q", (L, T, nq * hd), torch.bfloat16), k=b("t.k", (L, T, nkv * hd), torch.bfloat16),
                   v=b("t.v", (L, T, nkv * hd), torch.bfloat16), att=b("t.att", (L, T, nq * hd), torch.bfloat16),
@@ -214,7 +213,7 @@ class Trainer:
             n = min(rc, R - r0)
             self._gemm(hn[r0:r0 + n], "lm_head", None, lg, n, EPI_F32)
             lib.call("vr2_lse_gather", lg, lg.stride(0), n, V, tok[r0:r0 + n], temperature, logp[r0:r0 + n], lse_out[r0:r0 + n], eng.s)
-        self._saved = dict(sv=sv, S=S, G=G, C=C, T=T, cos=cos, sin=sin, work=d_work, work_dq=work_dq, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
+        self._saved = dict(sv=sv, S=S, G=G, C=C, T=T, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
                            lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None)
         return logp.view(G, C)
 
@@ -288,7 +287,7 @@ class Trainer:
             att, q, k, v, lse = sv["att"][l], sv["q"][l], sv["k"][l], sv["v"][l], sv["lse"][l]
             self._wgrad(dxb, att, f"l{l}.o_w", H, nq * hd, T)
             lib.call("vr2_attn_delta", att, datt, att.stride(0), T, nq, hd, lse, rowc, eng.s)
-            lib.call("vr2_attn_bwd_dq", s["work_dq"], s["work_dq"].shape[0], q, q.stride(0), k, v, k, v, k.stride(0), datt, rowc, T, dq,
+            lib.call("vr2_attn_bwd_dq", s["work"], s["work"].shape[0], q, q.stride(0), k, v, k, v, k.stride(0), datt, rowc, T, dq,
                      nq, t.group, hd, scale, eng.s)
             dk.zero_(); dvv.zero_()
             lib.call("vr2_attn_bwd_dkv", s["kwork"], s["kwork"].shape[0], q, q.stride(0), k, v, k.stride(0), datt, rowc, T, dk, dvv,

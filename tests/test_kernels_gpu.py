@@ -118,11 +118,13 @@ def test_gemm_256_tile_swiglu_and_random(dev):
     assert (C.cpu() - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
 
 
-def test_gemm_main_plus_tail_split(dev):
+@pytest.mark.parametrize("K", [128, 2048])
+def test_gemm_main_plus_tail_split(dev, K):
     """M = 9 whole 256-row tiles + 64 tail rows with N = 7168: the full tiling (10 x 28 = 280 tiles, 1.09 rounds) is inefficient,
-    the 252 whole tiles fill one round -> 256-row kernel on rows [0, 2304) + 128-row kernel on the tail (gemm.hip launch)"""
+    the 252 whole tiles fill one round -> 256-row kernel on rows [0, 2304) + 128-row kernel on the tail (gemm.hip launch).
+    K = 2048: the fp32-output tails (56 tiles) are additionally cut into 4 k-parts that add atomically (exact on integers)."""
     from video_r2_amd.weights import interleave_gate_up
-    M, N, K = 2368, 7168, 128
+    M, N = 2368, 7168
     g = torch.Generator().manual_seed(4)
     A = torch.randint(-3, 4, (M, K), generator=g).float()
     W = torch.randint(-2, 3, (N, K), generator=g).float() + (torch.arange(N)[:, None] % 7 == 0).float()

@@ -28,7 +28,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {   // 16 B per l
 
 // epilogue shared by the tile variants: lane holds D[row n = 4*fq + r][col m = fr] of each 16x16 accumulator; mw / nw are the
 // wave's first output row / column
-template <int EPI, int MT>
+template <int EPI, int MT, bool ATOMIC = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, int n0, int wn, int fr, int fq,
                                          const float* __restrict__ bias, void* __restrict__ Cv, long ldc, int M, int N,
                                          bf16* __restrict__ aux, long ldaux) {
@@ -79,6 +79,10 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, in
         *reinterpret_cast<bf16x4*>((bf16*)Cv + (long)m * ldc + n) = o;
       } else {
         float* cp = (float*)Cv + (long)m * ldc + n;
+        if (ATOMIC) {   // one k-part of a split-K launch: the parts add into the (zeroed, or residual-holding) fp32 output
+          unsafeAtomicAdd(cp, v0); unsafeAtomicAdd(cp + 1, v1); unsafeAtomicAdd(cp + 2, v2); unsafeAtomicAdd(cp + 3, v3);
+          continue;
+        }
         if (EPI == EPI_ADD_F32) {
           const float4 old = *reinterpret_cast<const float4*>(cp);
           v0 += old.x; v1 += old.y; v2 += old.z; v3 += old.w;
@@ -91,7 +95,9 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, in
 
 // MT = 16-row activation fragments per wave: workgroup tile BM x 128 with BM = 32*MT (128 for big grids; 64 when the 128-row
 // grid would leave CUs with fewer than ~2 workgroups -- prefill at M = S ~ 1k rows, ViT projections with N = 1280)
-template <int EPI, int MT>
+// SPLIT: gridDim.z k-parts of a launch with too few output tiles to fill the chip (the < 256 tail rows of a 256-row tiling at
+// N = 3584 are 28 tiles, each walking the whole K: 0.47 ms at K = 37888 on 28 CUs); fp32 outputs only, the parts add atomically
+template <int EPI, int MT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ Wp,
                                                    int n_tiles, const float* __restrict__ bias, void* __restrict__ Cv,
                                                    long ldc, int M, int N, int K, bf16* __restrict__ aux, long ldaux) {
@@ -139,15 +145,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = K / BK;
+  int t_first = 0, nt = K / BK;
+  if (SPLIT) {
+    const int all = K / BK;
+    t_first = (int)((long)blockIdx.z * all / gridDim.z);
+    nt = (int)((long)(blockIdx.z + 1) * all / gridDim.z);
+    if (blockIdx.z != 0) bias = nullptr;
+  }
 #pragma unroll
-  for (int i = 0; i < NA; ++i) glds16(ga[i], smem + la[i]);
+  for (int i = 0; i < NA; ++i) glds16(ga[i] + (long)t_first * BK, smem + (t_first & 1) * BUF + la[i]);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) glds16(gw[i], smem + lw[i]);
+  for (int i = 0; i < 4; ++i) glds16(gw[i] + (long)t_first * 1024, smem + (t_first & 1) * BUF + lw[i]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  for (int t = t_first; t < nt; ++t) {
     char* cur = smem + (t & 1) * BUF;
     char* nxt = smem + ((t + 1) & 1) * BUF;
     if (t + 1 < nt) {   // stage tile t+1 BEFORE computing tile t: its HBM/L2 latency hides under the MFMA block
@@ -176,7 +188,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
     __syncthreads();                                   // ... for every wave, and tile t is fully consumed
   }
 
-  epilogue<EPI, MT>(acc, m0 + wm * (16 * MT), n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux);
+  epilogue<EPI, MT, SPLIT>(acc, m0 + wm * (16 * MT), n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux);
+}
+
+__global__ __launch_bounds__(256) void zero_rows_f32_kernel(float* __restrict__ C, long ldc, int N) {
+  float* row = C + (long)blockIdx.x * ldc;
+  for (int n = threadIdx.x * 4; n < N; n += 1024) *reinterpret_cast<float4*>(row + n) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- 256 x 256 x 64 tile, 8 waves (2 M x 4 N, 128 x 64 outputs each), for grids of >= 2 such tiles per CU ----------------
@@ -312,6 +329,27 @@ void launch128(const void* A, int64_t lda, const void* W, const void* bias, void
   }
 }
 
+// few rows (a tail of <= 128), fp32 output, long K: 64-row tiles with the k-tiles dealt to enough parts to fill the CUs
+template <int EPI>
+bool launch_tail_splitk(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
+                        int64_t K, void* stream) {
+  if constexpr (EPI == EPI_F32 || EPI == EPI_ADD_F32) {
+    const long nb = (N + BN - 1) / BN, mb = (M + 63) / 64, kt = K / BK;
+    long parts = 256 / (nb * mb);
+    if (parts > kt / 4) parts = kt / 4;
+    if (parts > 32) parts = 32;
+    if (parts < 2) return false;
+    if (EPI == EPI_F32) hipLaunchKernelGGL(zero_rows_f32_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, (float*)C, (long)ldc, (int)N);
+    dim3 grid((unsigned)nb, (unsigned)mb, (unsigned)parts);
+    hipLaunchKernelGGL((gemm_kernel<EPI, 2, true>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16*)A, (long)lda,
+                       (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, C, (long)ldc, (int)M, (int)N, (int)K,
+                       (bf16*)nullptr, 0L);
+    return true;
+  } else {
+    return false;
+  }
+}
+
 template <int EPI>
 void launch256(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
                int64_t K, void* stream, void* aux, int64_t ldaux) {
@@ -347,8 +385,9 @@ int launch(const void* A, int64_t lda, const void* W, const void* bias, void* C,
     launch256<EPI>(A, lda, W, bias, C, ldc, M, N, K, stream, aux, ldaux);
   } else if (!no256 && main >= 2048 && tail > 0 && tail <= 128 && eff256(main, N) >= 922) {
     launch256<EPI>(A, lda, W, bias, C, ldc, main, N, K, stream, aux, ldaux);
-    launch128<EPI>((const bf16*)A + main * lda, lda, W, bias, (char*)C + main * ldc * esz, ldc, tail, N, K, stream,
-                   aux ? (bf16*)aux + main * ldaux : nullptr, ldaux);
+    if (!launch_tail_splitk<EPI>((const bf16*)A + main * lda, lda, W, bias, (char*)C + main * ldc * esz, ldc, tail, N, K, stream))
+      launch128<EPI>((const bf16*)A + main * lda, lda, W, bias, (char*)C + main * ldc * esz, ldc, tail, N, K, stream,
+                     aux ? (bf16*)aux + main * ldaux : nullptr, ldaux);
   } else {
     launch128<EPI>(A, lda, W, bias, C, ldc, M, N, K, stream, aux, ldaux);
   }

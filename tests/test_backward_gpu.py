@@ -60,6 +60,21 @@ def test_gemm_tn_256_tile_exact(dev, K):
     assert torch.equal(C[:M].cpu(), 2 * ref) and (C[M] == 5.0).all()
 
 
+def test_gemm_tn_partial_last_round_splits_k(dev):
+    """1036 tiles of 256 x 256 = 4.05 rounds on 256 CUs: the (+)= launch runs 1024 tiles as they are and the last 12 as
+    tiles x k-parts with atomic adds (gemm_tn.hip); exact on small integers whatever the order of the adds"""
+    M, N, K = 3584, 18944, 1088                                  # 14 x 74 tiles; 17 k-tiles -> 2 k-parts
+    g = torch.Generator(device=dev).manual_seed(3)
+    A = torch.randint(-3, 4, (K, M), generator=g, device=dev).float()
+    B = torch.randint(-2, 3, (K, N), generator=g, device=dev).float()
+    ref = A.t() @ B
+    C = torch.full((M + 1, N), 5.0, device=dev)
+    lib.call("vr2_gemm_tn_bf16", A.to(torch.bfloat16), M, B.to(torch.bfloat16), N, C, N, M, N, K, 1, S())
+    assert torch.equal(C[:M], ref + 5.0) and (C[M] == 5.0).all()
+    lib.call("vr2_gemm_tn_bf16", A.to(torch.bfloat16), M, B.to(torch.bfloat16), N, C, N, M, N, K, 0, S())
+    assert torch.equal(C[:M], ref)
+
+
 def test_swiglu_fwd_bwd(dev):
     from video_r2_amd.weights import interleave_gate_up
     T, I = 37, 48

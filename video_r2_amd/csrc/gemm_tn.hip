@@ -123,27 +123,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16* __restrict__ A
 // applied to the per-lane SOURCE address of the load and again to the read address: every half-wave read covers all 64 banks once.
 // Phases / staging / counted vmcnt / wave stagger exactly as in gemm256_kernel (dY halves take the X role, x halves the W role).
 // K must be a multiple of 64 here (the host sends a k tail to the 128-tile kernel above).
-template <bool ACC>
+// A launch covers the tiles [tile0, tile0 + gridDim.x / kparts) of the grouped walk, each cut into kparts ranges of k-tiles
+// (kparts > 1 only with MODE 2).  MODE 0: C = ..., 1: C += ... (read-modify-write), 2: C += ... by fp32 atomics -- the last,
+// partly filled round of a tiling (1036 tiles on 256 CUs = 4.05 rounds) runs as tiles x k-parts that fill the chip instead.
+template <int MODE>
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ B, long ldb,
                                                          float* __restrict__ C, long ldc, int M, int N, int K, int tiles_m,
-                                                         int tiles_n) {
+                                                         int tiles_n, int tile0, int kparts) {
+  constexpr bool ACC = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((ext_vector_type(4))) __bf16 vb4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
   int bm, bn;
+  int kpart = 0;
   {
-    const int nb = tiles_m * tiles_n, id = blockIdx.x;
+    int nb = gridDim.x, id = blockIdx.x;
+    if (MODE == 2) { nb /= kparts; kpart = id % kparts; id /= kparts; }
     const int q = nb / 8, r = nb % 8, x = id % 8;
-    const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;   // bijective XCD remap
+    const int wg = tile0 + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;   // bijective XCD remap
     const int per_group = 8 * tiles_n, grp = wg / per_group, in_grp = wg % per_group;
     const int rows = (tiles_m - grp * 8) < 8 ? (tiles_m - grp * 8) : 8;
     bm = grp * 8 + in_grp % rows;
     bn = in_grp / rows;
   }
   const int m0 = bm * 256, n0 = bn * 256;
-  const int NT = K >> 6;
+  int NT = K >> 6;
+  if (MODE == 2) {   // this workgroup's k-tiles
+    const int t0 = (int)((long)kpart * NT / kparts), t1 = (int)((long)(kpart + 1) * NT / kparts);
+    A += (long)t0 * 64 * lda;
+    B += (long)t0 * 64 * ldb;
+    NT = t1 - t0;
+  }
   const bf16* ga[2][2];
   const bf16* gb[2][2];
 #pragma unroll
@@ -227,6 +239,25 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const bf16* __restrict_
   }
 #undef VR2_MMA
   if (wm == 0) __builtin_amdgcn_s_barrier();
+  if (MODE == 2) {
+    // atomic (+)=: the memory-side float atomics run at full rate only on whole 256-byte row segments per wave instruction, so
+    // the wave's 128 x 64 block goes through its own LDS region 32 rows at a time (272-byte row stride: conflict-free writes)
+    float* stg = reinterpret_cast<float*>(smem + wave * 8704);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int in = 0; in < 4; ++in)
+          *reinterpret_cast<f32x4*>(stg + (j * 16 + fr) * 68 + in * 16 + fq * 4) = acc[in][p * 2 + j];
+      const int n = n0 + wn * 64 + lane;
+      for (int rr = 0; rr < 32; ++rr) {
+        const int m = m0 + wm * 128 + p * 32 + rr;
+        if (m < M && n < N) unsafeAtomicAdd(C + (long)m * ldc + n, stg[rr * 68 + lane]);
+      }
+    }
+    return;
+  }
   // (+)= epilogue: the 8 reads of a column group are issued together, then added and stored (one read-wait-store at a time left
   // the workgroup's 512 KiB of fp32 read-modify-write latency-bound)
 #pragma unroll
@@ -267,17 +298,30 @@ extern "C" int vr2_gemm_tn_bf16(const void* A_bf16, int64_t lda, const void* B_b
   if (!no256 && K >= 256 && M >= 128 && N >= 128 && t256 * 4 >= 3 * rounds * 256) {
     static bool attr256 = false;
     if (!attr256) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       attr256 = true;
     }
     const int64_t Kmain = K / 64 * 64;
+    // (+)= with more than one round whose last round is under 60 % full: that round's tiles run as tiles x k-parts with atomic
+    // adds (>= 8 k-tiles per part), the whole rounds before it as they are
+    long tail_tiles = t256 % 256, parts = 0;
+    if (accumulate && t256 > 256 && tail_tiles > 0 && tail_tiles * 10 < 256 * 6) {
+      parts = 256 / tail_tiles;
+      if (parts > Kmain / 64 / 8) parts = Kmain / 64 / 8;
+    }
+    const long main_tiles = parts >= 2 ? t256 - tail_tiles : t256;
     if (accumulate)
-      hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3((unsigned)t256), dim3(512), 131072, s, (const bf16*)A_bf16, (long)lda,
-                         (const bf16*)B_bf16, (long)ldb, (float*)C_f32, (long)ldc, (int)M, (int)N, (int)Kmain, (int)tm, (int)tn);
+      hipLaunchKernelGGL(gemm_tn256_kernel<1>, dim3((unsigned)main_tiles), dim3(512), 131072, s, (const bf16*)A_bf16, (long)lda,
+                         (const bf16*)B_bf16, (long)ldb, (float*)C_f32, (long)ldc, (int)M, (int)N, (int)Kmain, (int)tm, (int)tn, 0, 1);
     else
-      hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3((unsigned)t256), dim3(512), 131072, s, (const bf16*)A_bf16, (long)lda,
-                         (const bf16*)B_bf16, (long)ldb, (float*)C_f32, (long)ldc, (int)M, (int)N, (int)Kmain, (int)tm, (int)tn);
+      hipLaunchKernelGGL(gemm_tn256_kernel<0>, dim3((unsigned)main_tiles), dim3(512), 131072, s, (const bf16*)A_bf16, (long)lda,
+                         (const bf16*)B_bf16, (long)ldb, (float*)C_f32, (long)ldc, (int)M, (int)N, (int)Kmain, (int)tm, (int)tn, 0, 1);
+    if (parts >= 2)
+      hipLaunchKernelGGL(gemm_tn256_kernel<2>, dim3((unsigned)(tail_tiles * parts)), dim3(512), 131072, s, (const bf16*)A_bf16,
+                         (long)lda, (const bf16*)B_bf16, (long)ldb, (float*)C_f32, (long)ldc, (int)M, (int)N, (int)Kmain, (int)tm,
+                         (int)tn, (int)main_tiles, (int)parts);
     if (vr2_check_launch("vr2_gemm_tn_bf16(256)")) return -1;
     if (Kmain == K) return 0;
     A_bf16 = (const bf16*)A_bf16 + Kmain * lda;

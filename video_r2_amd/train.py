@@ -206,7 +206,7 @@ class Trainer:
         eng._norm(hs, W["norm"], hn, R, H, t.rms_norm_eps)
         logp = b("t.logp", (R,), torch.float32)
         lse_out = b("t.lse_out", (R,), torch.float32)
-        rc = min(1024, R)
+        rc = min(4096, R)        # rows per logits chunk: 4096 x 152064 fp32 = 2.5 GB; keeps the head GEMMs on 256-row tiles
         lg = b("lm.chunk_logits", (rc, V), torch.float32)
         tok = comp.view(-1)
         for r0 in range(0, R, rc):
@@ -236,7 +236,7 @@ class Trainer:
         dl = dlogp.reshape(-1).to(torch.float32).contiguous()
         # ---- log-prob head
         Vp = W.shape["lm_head_t"][1]
-        rc = min(1024, R)
+        rc = min(4096, R)        # rows per logits chunk: 4096 x 152064 fp32 = 2.5 GB; keeps the head GEMMs on 256-row tiles
         lg = b("lm.chunk_logits", (rc, V), torch.float32)
         dz = b("t.dz", (rc, Vp), torch.bfloat16)
         dhn = b("t.dhn", (R, H), torch.float32)

@@ -482,6 +482,25 @@ def main():
         extra["roofline_training_gemm"] = {"bound": "mfma", "kernel": gname + " (gate/up GEMM + SwiGLU, %d x %d x %d)" % (Tr, n_gu, H),
                                            "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": g_tf / 2500.0, "traffic": None,
                                            "avg_launch_us": g_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H}
+        # the weight-gradient GEMM of the same layer (dW[2I][H] += dY[T][2I]^T X[T][H]): the largest launch of the backward
+        if hasattr(upd, "state") and "l0.gu_w" in getattr(upd.state, "grad", {}):
+            dya = torch.randn(Tr, n_gu, device=device).to(torch.bfloat16)
+            gw_ = upd.state.grad["l0.gu_w"]
+            keep = gw_.clone()
+            wreps = 3
+            lib.call("vr2_gemm_tn_bf16", dya, n_gu, xa, H, gw_, gw_.stride(0), n_gu, H, Tr, 1, eng.s)
+            L.vr2_event_record(e0, ctypes.c_void_p(eng.s))
+            for _ in range(wreps):
+                lib.call("vr2_gemm_tn_bf16", dya, n_gu, xa, H, gw_, gw_.stride(0), n_gu, H, Tr, 1, eng.s)
+            L.vr2_event_record(e1, ctypes.c_void_p(eng.s))
+            eng.sync()
+            w_ms = elapsed(e0, e1) / wreps
+            gw_.copy_(keep)
+            w_tf = 2.0 * Tr * n_gu * H / (w_ms * 1e-3) / 1e12
+            extra["roofline_wgrad"] = {"bound": "mfma", "kernel": "gemm_tn256_kernel<1> (+ <2>: last round as k-parts) (gate/up weight gradient, %d x %d x %d, fp32 +=)" % (n_gu, H, Tr),
+                                       "achieved": w_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": w_tf / 2500.0, "traffic": None,
+                                       "avg_launch_us": w_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H}
+            del dya, keep
         del xa, ya
 
     if rank == 0:

@@ -360,12 +360,12 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
       gw[h][i] = Wp + ((long)nt * ksteps + (piece & 1)) * 512 + lane * 8;
     }
   auto stage_x = [&](int h, int T) {
-    if (T >= NT || (ABL & 4)) return;
+    if (T >= NT || (ABL & 4) || (ABL & 8)) return;
     char* dst = smem + (T & 1) * 65536 + h * 16384 + wave * 2048;
     glds16(gx[h][0] + (long)T * 64, dst); glds16(gx[h][1] + (long)T * 64, dst + 1024);
   };
   auto stage_w = [&](int h, int T) {
-    if (T >= NT || (ABL & 4)) return;
+    if (T >= NT || (ABL & 4) || (ABL & 16)) return;
     char* dst = smem + (T & 1) * 65536 + 32768 + h * 16384 + wave * 2048;
     glds16(gw[h][0] + (long)T * 1024, dst); glds16(gw[h][1] + (long)T * 1024, dst + 1024);
   };
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
   // prologue: half-tiles 0..5 (tile 0 complete + W of tile 1)
   stage_w(0, 0); stage_w(1, 0); stage_x(0, 0); stage_x(1, 0); stage_w(0, 1); stage_w(1, 1);
-  if (NT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (NT > 1) { if ((ABL & 8) || (ABL & 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();       // stagger: waves 4-7 run one slot behind
   bf16x8 Wf[4][2], Xs[4][2];
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
     __builtin_amdgcn_s_barrier();
     // ---- p3
     stage_w(1, T + 2);
-    if (T + 2 < NT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (T + 2 < NT) { if ((ABL & 8) || (ABL & 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -460,6 +460,7 @@ int main() {
     {1088, 4608, 3584, "prefill qkv"}, {1088, 3584, 3584, "prefill o"}, {1088, 37888, 3584, "prefill gate/up"}, {1088, 3584, 18944, "prefill down"}};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& s : shapes) {
+    if (getenv("VR2_BENCH_SHAPE") && !strstr(s.name, getenv("VR2_BENCH_SHAPE"))) continue;
     bf16 *A, *W, *C;
     const int nt16 = (s.N + 15) / 16;
     CK(hipMalloc(&A, (size_t)s.M * s.K * 2)); CK(hipMalloc(&W, (size_t)nt16 * 16 * s.K * 2)); CK(hipMalloc(&C, (size_t)s.M * s.N * 2));
@@ -522,6 +523,10 @@ int main() {
     run("v5 xcd no read+stage", [&] { hipLaunchKernelGGL((v5<1, 6>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     { static bool o = false; if (!o) { o = true; CK(hipFuncSetAttribute((const void*)v5<1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }
     run("v5 xcd no mfma+stage", [&] { hipLaunchKernelGGL((v5<1, 5>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+    { static bool o = false; if (!o) { o = true; CK(hipFuncSetAttribute((const void*)v5<1, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); CK(hipFuncSetAttribute((const void*)v5<1, 19>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }
+    run("v5 stage W only", [&] { hipLaunchKernelGGL((v5<1, 11>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+    run("v5 stage X only", [&] { hipLaunchKernelGGL((v5<1, 19>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+    if (getenv("VR2_BENCH_SHORT")) { CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); continue; }
     run("v2 128 3buf", [&] { hipLaunchKernelGGL((v2<4, 3>), grid, dim3(256), 3 * 32768, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     run("v2 64 2buf", [&] { hipLaunchKernelGGL((v2<2, 2>), grid64, dim3(256), 2 * 24576, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     run("v2 64 3buf", [&] { hipLaunchKernelGGL((v2<2, 3>), grid64, dim3(256), 3 * 24576, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });

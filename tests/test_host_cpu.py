@@ -310,3 +310,33 @@ def test_tiny_preset_matches_the_fixture_config():
     from tests.helpers import to_engine_cfg
     from video_r2_amd.config import ModelConfig
     assert ModelConfig.tiny() == to_engine_cfg(om.cfg_tiny(2))
+
+
+def test_key_work_covers_every_visible_pair_once():
+    """vr2_attn_bwd_dkv work list: every (key row, query row, q head of the GQA group) the causal / shared-prefix mask allows is
+    walked by exactly one item, whatever the cuts by query range and by heads; heaviest items come first."""
+    from video_r2_amd.host import vision_plan as vp
+    for (S, G, C, kt, qs, group, ms) in ((70, 2, 40, 128, 48, 2, 3), (300, 3, 200, 128, 256, 7, 8), (130, 2, 64, 64, 64, 4, 64), (1, 1, 1, 128, 512, 7, 64)):
+        T = S + G * C
+        allow = np.zeros((T, T), dtype=bool)                         # [query][key]
+        allow[:S, :S] = np.tril(np.ones((S, S), dtype=bool))
+        for g in range(G):
+            a = S + g * C
+            allow[a:a + C, :S] = True
+            allow[a:a + C, a:a + C] = np.tril(np.ones((C, C), dtype=bool))
+        kw = vp.key_work(S, G, C, k_tile=kt, q_split=qs, group=group, max_steps=ms)
+        assert kw.dtype == np.int32 and kw.shape[1] == 8 and (kw[:, 1] <= 128).all() and (kw[:, 1] >= 1).all()
+        seen = np.zeros((group, T, T), dtype=np.int32)
+        steps = []
+        for k0, nk, q1, l1, q2, l2, h0, nh in kw:
+            assert 1 <= nh <= group and 0 <= h0 and h0 + nh <= group
+            keys = np.arange(k0, k0 + nk)
+            for h in range(h0, h0 + nh):
+                if l1:
+                    q = np.arange(q1, q1 + l1)
+                    seen[h][np.ix_(q, keys)] += (keys[None, :] <= q[:, None])
+                if l2:
+                    seen[h][q2:q2 + l2, k0:k0 + nk] += 1
+            steps.append(nh * (-(-l1 // 64) + -(-l2 // 64)))
+        assert (seen == allow[None].astype(np.int32)).all()
+        assert steps == sorted(steps, reverse=True)

@@ -95,8 +95,9 @@ def test_swiglu_fwd_bwd(dev):
     assert (d[:, :, 1].reshape(T, I) - uq.grad).abs().max().item() <= 2 ** -8 * uq.grad.abs().max().item()
 
 
-def test_rmsnorm_bwd(dev):
-    M, H = 300, 512
+@pytest.mark.parametrize("M,H", [(300, 512), (1030, 3584), (4100, 2048), (70, 8192)])
+def test_rmsnorm_bwd(dev, M, H):
+    """one-pass kernel (rows + weight gradient, 1 / 4 / 8 rows per workgroup) for H <= 4096; two passes above"""
     g = torch.Generator().manual_seed(3)
     x = torch.randn(M, H, generator=g, requires_grad=True); w = (1 + 0.1 * torch.randn(H, generator=g)).requires_grad_()
     dy = torch.randn(M, H, generator=g)
@@ -106,6 +107,9 @@ def test_rmsnorm_bwd(dev):
     lib.call("vr2_rmsnorm_bwd", x.detach().to(dev), H, w.detach().to(dev), dy.to(dev), H, dx, H, rinv, dw, M, H, 1e-6, 1, S())
     assert (dx.cpu() - 1.0 - x.grad).abs().max().item() < 1e-5 * max(1.0, x.grad.abs().max().item())
     assert (dw.cpu() - w.grad).abs().max().item() < 1e-4 * w.grad.abs().max().item()
+    dx2 = torch.full((M, H), 1.0, device=dev)                      # no weight gradient, overwrite
+    lib.call("vr2_rmsnorm_bwd", x.detach().to(dev), H, w.detach().to(dev), dy.to(dev), H, dx2, H, None, None, M, H, 1e-6, 0, S())
+    assert (dx2.cpu() - x.grad).abs().max().item() < 1e-5 * max(1.0, x.grad.abs().max().item())
 
 
 def test_rope_bwd_is_transpose_of_forward(dev):

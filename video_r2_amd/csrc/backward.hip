@@ -85,6 +85,74 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   }
 }
 
+// Row part and weight-gradient part in ONE pass for H <= 4096: a workgroup walks `rows_per_block` rows, keeps each row's x and
+// dy in registers between the two block reductions and the dx store (read once instead of twice + once more by the column
+// pass), adds dy * x * inv into per-thread column sums, and at the end adds them into dw through LDS so that consecutive lanes
+// add consecutive floats (whole 256-byte segments per wave instruction: the shape float atomics run at full rate with).
+template <int NG>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                             const float* __restrict__ dy, long ldy, float* __restrict__ dx, long lddx,
+                                                             float* __restrict__ rinv, float* __restrict__ dw, int M, int H, float eps,
+                                                             int accumulate, int rows_per_block) {
+  __shared__ float scratch[8];
+  __shared__ __attribute__((aligned(16))) float cols[NG * 1024];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  float4 wv[NG], acc[NG];
+  bool ok[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int i = tid * 4 + j * 1024;
+    ok[j] = i < H;
+    wv[j] = ok[j] ? *reinterpret_cast<const float4*>(w + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  for (int m = r0; m < r1; ++m) {
+    const float* xr = x + (long)m * ldx;
+    const float* dyr = dy + (long)m * ldy;
+    float4 xv[NG], dv[NG];
+    float ss = 0.f, dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int i = tid * 4 + j * 1024;
+      xv[j] = ok[j] ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dv[j] = ok[j] ? *reinterpret_cast<const float4*>(dyr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ss += xv[j].x * xv[j].x + xv[j].y * xv[j].y + xv[j].z * xv[j].z + xv[j].w * xv[j].w;
+      dot += xv[j].x * wv[j].x * dv[j].x + xv[j].y * wv[j].y * dv[j].y + xv[j].z * wv[j].z * dv[j].z + xv[j].w * wv[j].w * dv[j].w;
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    __syncthreads();
+    if ((tid & 63) == 0) { scratch[wave] = ss; scratch[4 + wave] = dot; }
+    __syncthreads();
+    ss = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    dot = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+    const float inv = rsqrtf(ss / (float)H + eps);
+    const float coef = inv * inv * inv * dot / (float)H;
+    if (rinv && tid == 0) rinv[m] = inv;
+    float* dxr = dx + (long)m * lddx;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      if (!ok[j]) continue;
+      const int i = tid * 4 + j * 1024;
+      float4 o = make_float4(inv * wv[j].x * dv[j].x - xv[j].x * coef, inv * wv[j].y * dv[j].y - xv[j].y * coef,
+                             inv * wv[j].z * dv[j].z - xv[j].z * coef, inv * wv[j].w * dv[j].w - xv[j].w * coef);
+      if (accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(dxr + i);
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      *reinterpret_cast<float4*>(dxr + i) = o;
+      acc[j].x += dv[j].x * xv[j].x * inv; acc[j].y += dv[j].y * xv[j].y * inv;
+      acc[j].z += dv[j].z * xv[j].z * inv; acc[j].w += dv[j].w * xv[j].w * inv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NG; ++j) *reinterpret_cast<float4*>(cols + tid * 4 + j * 1024) = acc[j];
+  __syncthreads();
+  for (int i = tid; i < H; i += 256) unsafeAtomicAdd(dw + i, cols[i]);
+}
+
 // dw[h] += sum_m dy[m][h] * x[m][h] * rinv[m]      (column pass; grid over 256-column blocks x row slabs, fp32 atomics per slab)
 __global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ dy, long ldy,
                                                          const float* __restrict__ rinv, float* __restrict__ dw, int M, int H,
@@ -195,6 +263,19 @@ extern "C" int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32
                                void* stream) {
   VR2_REQUIRE(M >= 1 && H % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0, "vr2_rmsnorm_bwd: bad shape");
   VR2_REQUIRE(dw_f32 == nullptr || rinv_f32 != nullptr, "vr2_rmsnorm_bwd: dw needs the rinv scratch");
+  if (dw_f32 && H <= 4096) {   // one pass: rows and the weight gradient
+    const int rpb = M >= 4096 ? 8 : (M >= 1024 ? 4 : 1);
+    const unsigned nb = (unsigned)((M + rpb - 1) / rpb);
+    if (H <= 2048)
+      hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel<2>, dim3(nb), dim3(256), 0, STREAM, (const float*)x_f32, (long)ldx, (const float*)w_f32,
+                         (const float*)dy_f32, (long)ldy, (float*)dx_f32, (long)lddx, (float*)rinv_f32, (float*)dw_f32, (int)M, (int)H, eps,
+                         accumulate, rpb);
+    else
+      hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel<4>, dim3(nb), dim3(256), 0, STREAM, (const float*)x_f32, (long)ldx, (const float*)w_f32,
+                         (const float*)dy_f32, (long)ldy, (float*)dx_f32, (long)lddx, (float*)rinv_f32, (float*)dw_f32, (int)M, (int)H, eps,
+                         accumulate, rpb);
+    return vr2_check_launch("vr2_rmsnorm_bwd(rows + dw)");
+  }
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)M), dim3(256), 0, STREAM, (const float*)x_f32, (long)ldx,
                      (const float*)w_f32, (const float*)dy_f32, (long)ldy, (float*)dx_f32, (long)lddx, (float*)rinv_f32, (int)H, eps,
                      accumulate);

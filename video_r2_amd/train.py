@@ -173,11 +173,12 @@ class Trainer:
                   q=b("t.q", (L, T, nq * hd), torch.bfloat16), k=b("t.k", (L, T, nkv * hd), torch.bfloat16),
                   v=b("t.v", (L, T, nkv * hd), torch.bfloat16), att=b("t.att", (L, T, nq * hd), torch.bfloat16),
                   lse=b("t.lse", (L, T, nq), torch.float32), x_mid=b("t.x_mid", (L, T, H), torch.float32),
-                  xn2=b("t.xn2", (L, T, H), torch.bfloat16), gu=b("t.gu", (L, T, 2 * I16), torch.bfloat16))
+                  xn2=b("t.xn2", (L, T, H), torch.bfloat16), gu=b("t.gu", (L, T, 2 * I16), torch.bfloat16),
+                  act=b("t.acts", (L, T, I16), torch.bfloat16))   # SwiGLU output kept for the down-projection wgrad (9.8 GB at 7B)
         qkv32 = b("t.qkv32", (T, nqkv), torch.float32)
-        act = b("t.act", (T, I16), torch.bfloat16)
         scale = hd ** -0.5
         for l in range(L):
+            act = sv["act"][l]
             sv["x_in"][l].copy_(x)
             xn1 = sv["xn1"][l]
             eng._norm(x, W[f"l{l}.ln1"], xn1, T, H, t.rms_norm_eps)
@@ -259,7 +260,6 @@ class Trainer:
         dx[S - 1].copy_(dv_[:, 0].sum(0))
         dxb = b("t.dxb", (T, H), torch.bfloat16)
         dact = b("t.dact", (T, I16), torch.bfloat16)
-        act = b("t.act", (T, I16), torch.bfloat16)
         dgu = b("t.dgu", (T, 2 * I16), torch.bfloat16)
         dxn = b("t.dxn", (T, H), torch.float32)
         datt = b("t.datt", (T, nq * hd), torch.bfloat16)
@@ -274,8 +274,7 @@ class Trainer:
             self._cast(dx, dxb, T, H)
             self._gemm(dxb, f"l{l}.down_w_t", None, dact, T, EPI_BF16)
             gu = sv["gu"][l]
-            lib.call("vr2_swiglu_fwd", gu, gu.stride(0), act, act.stride(0), T, I16, eng.s)
-            self._wgrad(dxb, act, f"l{l}.down_w", H, I16, T)
+            self._wgrad(dxb, sv["act"][l], f"l{l}.down_w", H, I16, T)
             lib.call("vr2_swiglu_bwd", gu, gu.stride(0), dact, dact.stride(0), dgu, dgu.stride(0), T, I16, eng.s)
             self._gemm(dgu, f"l{l}.gu_w_t", None, dxn, T, EPI_F32)
             self._wgrad(dgu, sv["xn2"][l], f"l{l}.gu_w", 2 * I16, H, T)

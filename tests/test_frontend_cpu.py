@@ -189,3 +189,29 @@ def test_processing_front_end_builds_the_prompt_the_engine_expects(tmp_path, mon
     bad = {"prompt": [{"role": "user", "content": [{"type": "text", "text": "no clip but a <|video_pad|> string"}]}]}
     with pytest.raises(ValueError, match="video placeholders"):
         pf(bad)
+
+
+def test_eval_frame_plan_two_stage_selection():
+    """the harness's frame cut on top of the qwen-vl policy (eval/lmms-eval/lmms_eval/models/qwen2_5_vl.py:285-291):
+    truncating linspace over the stage-one frames, last frame appended when missing, repeats when the clip is short"""
+    from video_r2_amd.eval_adapter import eval_frame_plan
+    from video_r2_amd.host import frames as hf
+    ele = {"video": "x.mp4", "min_pixels": 4704, "max_pixels": 4704}
+    # 300 frames at 30 fps: stage one = 2 fps -> 20 frames; 8 of them + the last
+    idx, sfps, dims = eval_frame_plan(ele, 300, 30.0, 56, 84, 8)
+    n1 = hf.smart_nframes(ele, total_frames=300, video_fps=30.0)
+    one = np.asarray(hf.frame_indices(300, n1).tolist())
+    pos = np.linspace(0, n1 - 1, 8, dtype=int)
+    assert n1 == 20 and (idx[:8] == one[pos]).all() and len(idx) == 8 and idx[-1] == 299          # linspace hits n1 - 1 itself
+    assert abs(sfps - 2.0) < 1e-9 and dims == (56, 84)
+    idx, _, _ = eval_frame_plan(ele, 300, 30.0, 56, 84, 3)
+    assert idx.tolist() == [one[0], one[9], one[19]]
+    # one position misses the last stage-one frame: it is appended
+    idx, _, _ = eval_frame_plan(ele, 300, 30.0, 56, 84, 1)
+    assert idx.tolist() == [one[0], one[19]]
+    pos7 = np.linspace(0, 19, 7, dtype=int)
+    idx, _, _ = eval_frame_plan(ele, 300, 30.0, 56, 84, 7)
+    assert idx.tolist() == one[pos7].tolist() and pos7[-1] == 19
+    # a short clip: 4 stage-one frames, 6 wanted -> repeats, as indexing with the reference's linspace does
+    idx, _, _ = eval_frame_plan(ele, 8, 4.0, 56, 84, 6)
+    assert len(idx) == 6 and len(set(idx.tolist())) < 6 and idx[-1] == 7

@@ -362,6 +362,15 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
   auto stage_x = [&](int h, int T) {
     if (T >= NT || (ABL & 4) || (ABL & 8)) return;
     char* dst = smem + (T & 1) * 65536 + h * 16384 + wave * 2048;
+    if (ABL & 32) {   // timing only: the same bytes as pieces of 4 rows x 256 B (two k-tiles of 64 rows) instead of 8 rows x 128 B
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int piece = wave * 2 + i, row = (T & 1) * 64 + piece * 4 + (lane >> 4);
+        int am = m0 + h * 128 + row; if (am > M - 1) am = M - 1;
+        glds16(A + (long)am * lda + (long)(T & ~1) * 64 + (lane & 15) * 8, dst + i * 1024);
+      }
+      return;
+    }
     glds16(gx[h][0] + (long)T * 64, dst); glds16(gx[h][1] + (long)T * 64, dst + 1024);
   };
   auto stage_w = [&](int h, int T) {
@@ -526,6 +535,9 @@ int main() {
     { static bool o = false; if (!o) { o = true; CK(hipFuncSetAttribute((const void*)v5<1, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); CK(hipFuncSetAttribute((const void*)v5<1, 19>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }
     run("v5 stage W only", [&] { hipLaunchKernelGGL((v5<1, 11>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     run("v5 stage X only", [&] { hipLaunchKernelGGL((v5<1, 19>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+    { static bool o = false; if (!o) { o = true; CK(hipFuncSetAttribute((const void*)v5<1, 51>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); CK(hipFuncSetAttribute((const void*)v5<1, 35>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }
+    run("v5 stage X only, 4x256B", [&] { hipLaunchKernelGGL((v5<1, 51>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+    run("v5 stage both, X 4x256B", [&] { hipLaunchKernelGGL((v5<1, 35>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     if (getenv("VR2_BENCH_SHORT")) { CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); continue; }
     run("v2 128 3buf", [&] { hipLaunchKernelGGL((v2<4, 3>), grid, dim3(256), 3 * 32768, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     run("v2 64 2buf", [&] { hipLaunchKernelGGL((v2<2, 2>), grid64, dim3(256), 2 * 24576, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });

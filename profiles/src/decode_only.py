@@ -1,5 +1,5 @@
 """Decode-only run at 7B for profiling: P prompt groups x G=8 rows, C new tokens (graph replay)."""
-import sys, time, torch
+import os, sys, time, torch
 sys.path.insert(0, '.')
 from bench import model_cfg, synth_prompt
 from video_r2_amd import lib, weights as W
@@ -23,8 +23,8 @@ states = []
 for p_, (px, grid, ids) in enumerate(prompts):
     emb, plan = eng.encode_video(px, [grid])
     states.append(eng.prefill(pol, ids, emb.clone(), plan, [1.0], tag="pol", prefix_out=slots[p_]))
-for rep in range(2):
+for rep in range(1 if os.environ.get('VR2_NO_GRAPH') else 2):
     eng.sync(); t0 = time.perf_counter()
-    toks, _ = eng.decode(pol, states, 8, C, temperature=0.9, top_k=50, seed=rep, eos_token_id=None)
+    toks, _ = eng.decode(pol, states, 8, C, temperature=0.9, top_k=50, seed=rep, eos_token_id=None, use_graph=not os.environ.get('VR2_NO_GRAPH'))
     eng.sync(); dt = time.perf_counter() - t0
     print(f"P={P} rows={8*P} C={C} {MODE}: {dt*1e3/C:.3f} ms/token", flush=True)

@@ -182,11 +182,25 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const bf16* __restrict_
     glds(gb[h][1] + (long)T * 64 * ldb, dst + 1024);
   };
   f32x4 acc[4][8];
+  // (+)=: the accumulators START from the old dW values -- 32 reads in flight beside the prologue's direct-to-LDS loads, one
+  // exposed latency per tile -- so the epilogue only stores (a read-add-store epilogue paid four read latencies per tile)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ACC) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4, m = m0 + wm * 128 + j * 16 + fr;
+        if (n < N && m < M) acc[i][j] = *reinterpret_cast<const f32x4*>(C + (long)m * ldc + n);
+      }
+    }
   stage_b(0, 0); stage_b(1, 0); stage_a(0, 0); stage_a(1, 0); stage_b(0, 1); stage_b(1, 1);
+  if (ACC) {   // wait for them here: inside the loop the compiler's (uncounted-for) vmcnt would drain the staging loads each k-tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+  }
   if (NT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -258,27 +272,15 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(const bf16* __restrict_
     }
     return;
   }
-  // (+)= epilogue: the 8 reads of a column group are issued together, then added and stored (one read-wait-store at a time left
-  // the workgroup's 512 KiB of fp32 read-modify-write latency-bound)
+  // epilogue: stores only (MODE 1 started from the old values)
 #pragma unroll
   for (int in = 0; in < 4; ++in) {
     const int n = n0 + wn * 64 + in * 16 + fq * 4;
-    const bool nok = n < N;
-    float4 o[8];
-    float* cp[8];
-    bool ok[8];
+    if (n >= N) continue;
 #pragma unroll
     for (int im = 0; im < 8; ++im) {
       const int m = m0 + wm * 128 + im * 16 + fr;
-      ok[im] = nok && m < M;
-      cp[im] = C + (long)(ok[im] ? m : 0) * ldc + (nok ? n : 0);
-      if (ACC) o[im] = ok[im] ? *reinterpret_cast<const float4*>(cp[im]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int im = 0; im < 8; ++im) {
-      float4 v = make_float4(acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]);
-      if (ACC) { v.x += o[im].x; v.y += o[im].y; v.z += o[im].z; v.w += o[im].w; }
-      if (ok[im]) *reinterpret_cast<float4*>(cp[im]) = v;
+      if (m < M) *reinterpret_cast<f32x4*>(C + (long)m * ldc + n) = acc[in][im];
     }
   }
 }

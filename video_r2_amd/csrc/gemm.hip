@@ -28,19 +28,30 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {   // 16 B per l
 
 // epilogue shared by the tile variants: lane holds D[row n = 4*fq + r][col m = fr] of each 16x16 accumulator; mw / nw are the
 // wave's first output row / column
-template <int EPI, int MT, bool ATOMIC = false>
+// PRELOADED: the accumulators of an EPI_ADD_F32 launch started from the old output values, nothing is read back here
+template <int EPI, int MT, bool ATOMIC = false, bool PRELOADED = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, int n0, int wn, int fr, int fq,
                                          const float* __restrict__ bias, void* __restrict__ Cv, long ldc, int M, int N,
                                          bf16* __restrict__ aux, long ldaux) {
   if (EPI == EPI_SWIGLU_BF16) {
     // weight tiles alternate gate / up (weights.py interleave_gate_up): acc[2j] = gate, acc[2j+1] = up of the SAME 16
     // output columns, held by the same lane -> act = silu(gate + bg) * (up + bu), one rounding, no gate/up round trip
+    float4 bgs[2], bus[2];   // bias reads first and waited for once (see the generic path below)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ng = nw + (2 * j) * 16 + fq * 4;
+      const bool ld = bias && ng < N;
+      bgs[j] = ld ? *reinterpret_cast<const float4*>(bias + ng) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bus[j] = ld ? *reinterpret_cast<const float4*>(bias + ng + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      asm volatile("" ::"v"(bgs[j].x), "v"(bgs[j].y), "v"(bgs[j].z), "v"(bgs[j].w), "v"(bus[j].x), "v"(bus[j].y), "v"(bus[j].z), "v"(bus[j].w));
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ng = nw + (2 * j) * 16 + fq * 4;      // interleaved-space row of the gate values
       if (ng >= N) continue;
-      float4 bg = make_float4(0.f, 0.f, 0.f, 0.f), bu = bg;
-      if (bias) { bg = *reinterpret_cast<const float4*>(bias + ng); bu = *reinterpret_cast<const float4*>(bias + ng + 16); }
+      const float4 bg = bgs[j], bu = bus[j];
       const int no = (nw >> 5) * 16 + j * 16 + fq * 4;  // output column
 #pragma unroll
       for (int im = 0; im < MT; ++im) {
@@ -61,12 +72,21 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, in
     }
     return;
   }
+  float4 bvs[4];   // all bias reads before the first store: a read between store groups makes the compiler wait for the stores too
+#pragma unroll
+  for (int in = 0; in < 4; ++in) {
+    const int n = nw + in * 16 + fq * 4;
+    bvs[in] = (bias && n < N) ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // ... and waited for HERE: behind the per-row branches below the wait-count pass no longer knows the reads have landed and
+  // puts s_waitcnt vmcnt(0) in front of every store, i.e. one memory round trip per 16 x 4 block, 32 in a row per thread
+#pragma unroll
+  for (int in = 0; in < 4; ++in) asm volatile("" ::"v"(bvs[in].x), "v"(bvs[in].y), "v"(bvs[in].z), "v"(bvs[in].w));
 #pragma unroll
   for (int in = 0; in < 4; ++in) {
     const int n = nw + in * 16 + fq * 4;
     if (n >= N) continue;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+    const float4 bv = bvs[in];
 #pragma unroll
     for (int im = 0; im < MT; ++im) {
       const int m = mw + im * 16 + fr;
@@ -83,7 +103,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, in
           unsafeAtomicAdd(cp, v0); unsafeAtomicAdd(cp + 1, v1); unsafeAtomicAdd(cp + 2, v2); unsafeAtomicAdd(cp + 3, v3);
           continue;
         }
-        if (EPI == EPI_ADD_F32) {
+        if (EPI == EPI_ADD_F32 && !PRELOADED) {
           const float4 old = *reinterpret_cast<const float4*>(cp);
           v0 += old.x; v1 += old.y; v2 += old.z; v3 += old.w;
         }
@@ -256,12 +276,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16* __restrict__ A
     glds16(gw[h][1] + (long)T * 1024, dst + 1024);
   };
   f32x4 acc[4][8];
+  // residual-add epilogue: the accumulators START from the old output (32 reads in flight beside the prologue's loads, waited for
+  // once, before the loop) -- a read-add-store epilogue costs a memory round trip per 16 x 4 block, 32 per thread, after the k-loop
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_ADD_F32) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4, m = m0 + wm * 128 + j * 16 + fr;
+        if (n < N && m < M) acc[i][j] = *reinterpret_cast<const f32x4*>((const float*)Cv + (long)m * ldc + n);
+      }
+    }
   // prologue: tile 0 and the W halves of tile 1
   stage_w(0, 0); stage_w(1, 0); stage_x(0, 0); stage_x(1, 0); stage_w(0, 1); stage_w(1, 1);
+  if (EPI == EPI_ADD_F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+  }
   if (NT > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -308,7 +342,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16* __restrict__ A
   }
 #undef VR2_MMA
   if (wm == 0) __builtin_amdgcn_s_barrier();        // pairs with the stagger barrier of waves 4-7
-  epilogue<EPI, 8>(acc, m0 + wm * 128, n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux);
+  epilogue<EPI, 8, false, true>(acc, m0 + wm * 128, n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux);
 }
 
 template <int EPI>

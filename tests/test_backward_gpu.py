@@ -157,7 +157,8 @@ def test_dlogits_embed_bwd_colsum(dev):
 
 
 @pytest.mark.parametrize("group,Sp,C,G,ktile,qsplit", [(2, 70, 40, 2, 128, 48), (7, 70, 40, 2, 64, 48), (7, 300, 200, 3, 128, 256),
-                                                       (4, 256, 128, 2, 128, 128)])
+                                                       (4, 256, 128, 2, 128, 128), (7, 1, 1, 1, 128, 512), (2, 129, 65, 2, 128, 64),
+                                                       (1, 33, 3, 4, 128, 512)])
 def test_attention_backward_vs_autograd(dev, group, Sp, C, G, ktile, qsplit):
     """Unified rows: S prompt rows (causal) + G sequences of C completion rows (prefix visible + own causal), GQA."""
     from video_r2_amd.host import vision_plan as vp
@@ -204,7 +205,7 @@ def test_attention_backward_vs_autograd(dev, group, Sp, C, G, ktile, qsplit):
     lib.call("vr2_attn_bwd_dq", dwq, dwq.shape[0], qd, nH * hd, kd, vd, kd, vd, nKV * hd, dod, rowc, T, dq, nH, group, hd, scale, S())
     # small splits: several adders per prompt key row, by query range and by q heads
     kw = torch.from_numpy(vp.key_work(Sp, G, C, k_tile=ktile, q_split=qsplit, group=group, max_steps=3)).to(dev)
-    assert (kw[:, 7] < group).any().item()                                   # some items cover only part of the GQA group
+    assert group == 1 or Sp + C < 8 or (kw[:, 7] < group).any().item()     # some items cover only part of the GQA group
     dk = torch.zeros(T, nKV * hd, dtype=torch.float32, device=dev); dv = torch.zeros_like(dk)
     lib.call("vr2_attn_bwd_dkv", kw, kw.shape[0], qd, nH * hd, kd, vd, nKV * hd, dod, rowc, T, dk, dv, nH, group, hd, scale, S())
     # bf16 P / dS operands and bf16 outputs: 2^-6 of each gradient's scale

@@ -232,6 +232,41 @@ def _attn_ref(q, k, v, scale, allow):
     return torch.nan_to_num(s.softmax(-1)) @ v
 
 
+def test_attn_fwd128_edge_shapes(dev):
+    """head_dim-128 forward (attention_fwd.hip) at the edges of its tiling: one query row, a visible-only key source without a
+    causal part, 129 queries over 193 + 129 keys (partial last work item, partial last key tile in both sources), GQA group 7"""
+    from video_r2_amd.host import vision_plan as vp
+    hd, group, nKV = 128, 7, 1
+    nH = group * nKV
+    scale = hd ** -0.5
+    g = torch.Generator().manual_seed(9)
+    for (Sp, C) in ((0, 1), (5, 1), (193, 129), (64, 128), (300, 0)):
+        nq = C if C else 7
+        q = bf(torch.randn(nq, nH, hd, generator=g)); kp = bf(torch.randn(max(Sp, 1), nKV, hd, generator=g)); vp_ = bf(torch.randn(max(Sp, 1), nKV, hd, generator=g))
+        k = bf(torch.randn(nq, nKV, hd, generator=g)); v = bf(torch.randn(nq, nKV, hd, generator=g))
+        if C:      # prefix (all visible) + own causal rows
+            work = vp.causal_work(C, 0, 0, Sp, 0, q_tile=vp.LM_Q_TILE)
+            allow = torch.cat([torch.ones(C, Sp, dtype=torch.bool), torch.tril(torch.ones(C, C, dtype=torch.bool))], 1)
+            keys = torch.cat([kp[:Sp], k], 0); vals = torch.cat([vp_[:Sp], v], 0)
+        else:      # 7 queries that see the Sp prefix keys only
+            work = np.asarray([(0, nq, 0, Sp, 0, 0, 0, 0)], dtype=np.int32)
+            allow = torch.ones(nq, Sp, dtype=torch.bool)
+            keys, vals = kp, vp_
+        o = torch.full((nq + 1, nH * hd), 7.0, dtype=torch.bfloat16, device=dev)
+        lse = torch.zeros(nq, nH, device=dev)
+        lib.call("vr2_attn_tok", torch.from_numpy(np.ascontiguousarray(work)).to(dev), work.shape[0], q.reshape(nq, -1).to(dev), nH * hd,
+                 kp.reshape(kp.shape[0], -1).to(dev), vp_.reshape(kp.shape[0], -1).to(dev), k.reshape(nq, -1).to(dev), v.reshape(nq, -1).to(dev),
+                 nKV * hd, o, nH * hd, nH, group, hd, scale, lse, S())
+        assert (o[nq] == 7.0).all()                                          # nothing written past the last query row
+        oo = o[:nq].float().cpu().view(nq, nH, hd)
+        for h in range(nH):
+            s_ = (q[:, h].float() @ keys[:, 0].float().t()) * scale
+            s_ = s_.masked_fill(~allow, float("-inf"))
+            ref = s_.softmax(-1) @ vals[:, 0].float()
+            assert (oo[:, h] - ref).abs().max().item() < 2 ** -6 * max(1.0, ref.abs().max().item()), (Sp, C, h)
+            assert (lse[:, h].cpu() - torch.logsumexp(s_, -1)).abs().max().item() < 2e-3, (Sp, C, h)
+
+
 @pytest.mark.parametrize("hd", [80, 128])
 def test_attn_tok_varlen_and_causal(dev, hd):
     from video_r2_amd.host import vision_plan as vp

@@ -349,6 +349,7 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
   const int ksteps = K >> 5, NT = K >> 6;
   // staging sources: 2 pieces per wave per half-tile
   const bf16* gx[2][2]; const bf16* gw[2][2];
+  unsigned ox[2][2], ow[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -358,7 +359,11 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
       gx[h][i] = A + (long)am * lda + ((c ^ (row & 7)) << 3);
       int nt = (n0 >> 4) + h * 8 + (piece >> 1); if (nt > n_tiles - 1) nt = n_tiles - 1;
       gw[h][i] = Wp + ((long)nt * ksteps + (piece & 1)) * 512 + lane * 8;
+      ox[h][i] = (unsigned)(((long)am * lda + ((c ^ (row & 7)) << 3)) * 2);
+      ow[h][i] = (unsigned)((((long)nt * ksteps + (piece & 1)) * 512 + lane * 8) * 2);
     }
+  __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((long)M * lda * 2 > 0x7fffffffL ? 0x7fffffff : (long)M * lda * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)((long)n_tiles * 16 * K * 2 > 0x7fffffffL ? 0x7fffffff : (long)n_tiles * 16 * K * 2), 0x00020000);
   auto stage_x = [&](int h, int T) {
     if (T >= NT || (ABL & 4) || (ABL & 8)) return;
     char* dst = smem + (T & 1) * 65536 + h * 16384 + wave * 2048;
@@ -371,11 +376,21 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
       }
       return;
     }
+    if (ABL & 64) {   // buffer_load ... lds: 32-bit per-lane offset + scalar k-tile offset
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)dst, 16, ox[h][0], T * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(dst + 1024), 16, ox[h][1], T * 128, 0, 0);
+      return;
+    }
     glds16(gx[h][0] + (long)T * 64, dst); glds16(gx[h][1] + (long)T * 64, dst + 1024);
   };
   auto stage_w = [&](int h, int T) {
     if (T >= NT || (ABL & 4) || (ABL & 16)) return;
     char* dst = smem + (T & 1) * 65536 + 32768 + h * 16384 + wave * 2048;
+    if (ABL & 64) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)dst, 16, ow[h][0], T * 2048, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(dst + 1024), 16, ow[h][1], T * 2048, 0, 0);
+      return;
+    }
     glds16(gw[h][0] + (long)T * 1024, dst); glds16(gw[h][1] + (long)T * 1024, dst + 1024);
   };
   f32x4 acc[4][8];
@@ -538,6 +553,9 @@ int main() {
     { static bool o = false; if (!o) { o = true; CK(hipFuncSetAttribute((const void*)v5<1, 51>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); CK(hipFuncSetAttribute((const void*)v5<1, 35>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }
     run("v5 stage X only, 4x256B", [&] { hipLaunchKernelGGL((v5<1, 51>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     run("v5 stage both, X 4x256B", [&] { hipLaunchKernelGGL((v5<1, 35>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+    { static bool o = false; if (!o) { o = true; CK(hipFuncSetAttribute((const void*)v5<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); CK(hipFuncSetAttribute((const void*)v5<1, 67>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }
+    run("v5 full, buffer_load lds", [&] { hipLaunchKernelGGL((v5<1, 64>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+    run("v5 stage only, buffer_load lds", [&] { hipLaunchKernelGGL((v5<1, 67>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     if (getenv("VR2_BENCH_SHORT")) { CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); continue; }
     run("v2 128 3buf", [&] { hipLaunchKernelGGL((v2<4, 3>), grid, dim3(256), 3 * 32768, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     run("v2 64 2buf", [&] { hipLaunchKernelGGL((v2<2, 2>), grid64, dim3(256), 2 * 24576, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });

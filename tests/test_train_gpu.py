@@ -69,12 +69,16 @@ def _engine_grads_as_hf(tr, cfg):
     return {k: v.float().cpu() for k, v in out.items()}
 
 
-@pytest.mark.parametrize("group,loss_type", [(2, "bnpo"), (7, "grpo")])
-def test_forward_backward_vs_autograd(group, loss_type):
+@pytest.mark.parametrize("group,loss_type,keep_logits", [(2, "bnpo", True), (7, "grpo", True), (2, "bnpo", False)])
+def test_forward_backward_vs_autograd(group, loss_type, keep_logits):
+    """keep_logits False: the head backward recomputes the logits chunk by chunk (groups whose fp32 logits exceed
+    Trainer.KEEP_LOGITS_BYTES) instead of reading the ones forward() kept"""
     from video_r2_amd.host import grpo as hg
     from video_r2_amd.train import Trainer
     ocfg, eng, w, cfg, px, grid, prompt, comp = _setup(group, 40 + group)
     tr = Trainer(eng, eng.text)
+    if not keep_logits:
+        tr.KEEP_LOGITS_BYTES = 0
     emb, plan = eng.encode_video(torch.from_numpy(px).to(eng.device), [grid])
     lp = tr.forward(prompt, emb, plan, [1.0], comp, 0.9)
     G, C = comp.shape

@@ -97,6 +97,7 @@ class TrainState:
 
 class Trainer:
     """Training forward / backward / optimiser step on an Engine (shares its stream and workspaces)."""
+    KEEP_LOGITS_BYTES = 8 << 30      # forward() keeps a prompt group's fp32 logits for backward() up to this size
 
     def __init__(self, engine: Engine, text: Params):
         self.eng = engine
@@ -208,13 +209,19 @@ class Trainer:
         logp = b("t.logp", (R,), torch.float32)
         lse_out = b("t.lse_out", (R,), torch.float32)
         rc = min(4096, R)        # rows per logits chunk: 4096 x 152064 fp32 = 2.5 GB; keeps the head GEMMs on 256-row tiles
-        lg = b("lm.chunk_logits", (rc, V), torch.float32)
+        # the group's logits stay in memory for the backward when they fit KEEP_LOGITS_BYTES (7B, G x C = 8192 rows: 5 GB): the
+        # head backward then reads them instead of multiplying hn by the lm_head a second time
+        keep = R * V * 4 <= self.KEEP_LOGITS_BYTES
+        lg_all = b("t.logits", (R, V), torch.float32) if keep else None
+        lg = None if keep else b("lm.chunk_logits", (rc, V), torch.float32)
         tok = comp.view(-1)
         for r0 in range(0, R, rc):
             n = min(rc, R - r0)
+            if keep:
+                lg = lg_all[r0:r0 + n]
             self._gemm(hn[r0:r0 + n], "lm_head", None, lg, n, EPI_F32)
             lib.call("vr2_lse_gather", lg, lg.stride(0), n, V, tok[r0:r0 + n], temperature, logp[r0:r0 + n], lse_out[r0:r0 + n], eng.s)
-        self._saved = dict(sv=sv, S=S, G=G, C=C, T=T, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
+        self._saved = dict(logits=lg_all, sv=sv, S=S, G=G, C=C, T=T, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
                            lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None)
         return logp.view(G, C)
 
@@ -238,12 +245,16 @@ class Trainer:
         # ---- log-prob head
         Vp = W.shape["lm_head_t"][1]
         rc = min(4096, R)        # rows per logits chunk: 4096 x 152064 fp32 = 2.5 GB; keeps the head GEMMs on 256-row tiles
-        lg = b("lm.chunk_logits", (rc, V), torch.float32)
+        lg_all = s.get("logits")
+        lg = None if lg_all is not None else b("lm.chunk_logits", (rc, V), torch.float32)
         dz = b("t.dz", (rc, Vp), torch.bfloat16)
         dhn = b("t.dhn", (R, H), torch.float32)
         for r0 in range(0, R, rc):
             n = min(rc, R - r0)
-            self._gemm(s["hn"][r0:r0 + n], "lm_head", None, lg, n, EPI_F32)
+            if lg_all is not None:
+                lg = lg_all[r0:r0 + n]                                   # kept by forward()
+            else:
+                self._gemm(s["hn"][r0:r0 + n], "lm_head", None, lg, n, EPI_F32)
             lib.call("vr2_dlogits", lg, lg.stride(0), n, V, s["tok"][r0:r0 + n], s["lse_out"][r0:r0 + n], dl[r0:r0 + n],
                      s["temperature"], dz, dz.stride(0), eng.s)
             self._gemm(dz, "lm_head_t", None, dhn[r0:r0 + n], n, EPI_F32)

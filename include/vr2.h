@@ -184,9 +184,11 @@ int vr2_gemm_swiglu_save(const void* A_bf16, int64_t lda, const void* W_packed_b
 int vr2_swiglu_fwd(const void* gu_bf16, int64_t ldg, void* act_bf16, int64_t lda, int64_t T, int64_t I16, void* stream);
 int vr2_swiglu_bwd(const void* gu_bf16, int64_t ldg, const void* dact_bf16, int64_t ldd, void* dgu_bf16, int64_t ldo, int64_t T,
                    int64_t I16, void* stream);
-/* RMSNorm backward: dx (+)= d/dx of rmsnorm(x)*w against dy; dw += column sums (rinv = per-row scratch [M]) */
+/* RMSNorm backward: dx (+)= d/dx of rmsnorm(x)*w against dy; dw += column sums (rinv = per-row scratch [M]); dx_bf16: optional
+ * bf16 copy of the final dx rows (what the next dgrad / wgrad GEMMs read) */
 int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32, const void* dy_f32, int64_t ldy, void* dx_f32,
-                    int64_t lddx, void* rinv_f32, void* dw_f32, int64_t M, int64_t H, float eps, int accumulate, void* stream);
+                    int64_t lddx, void* rinv_f32, void* dw_f32, int64_t M, int64_t H, float eps, int accumulate,
+                    void* dx_bf16_or_null, int64_t lddb, void* stream);
 int vr2_colsum_bf16(const void* a_bf16, int64_t lda, void* out_f32, int64_t M, int64_t N, void* stream);
 /* inverse rotation of dq / dk, v passthrough -> packed [q|k|v] gradient rows */
 int vr2_rope_bwd(const void* dq_bf16, int64_t ldq, const void* dk_f32, const void* dv_f32, int64_t ldkv, const void* cos_f32,

@@ -104,11 +104,13 @@ def test_rmsnorm_bwd(dev, M, H):
     y = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
     y.backward(dy)
     dx = torch.full((M, H), 1.0, device=dev); rinv = torch.zeros(M, device=dev); dw = torch.zeros(H, device=dev)
-    lib.call("vr2_rmsnorm_bwd", x.detach().to(dev), H, w.detach().to(dev), dy.to(dev), H, dx, H, rinv, dw, M, H, 1e-6, 1, S())
+    dxb = torch.zeros(M, H + 8, dtype=torch.bfloat16, device=dev)   # optional bf16 copy of the final dx rows, own row stride
+    lib.call("vr2_rmsnorm_bwd", x.detach().to(dev), H, w.detach().to(dev), dy.to(dev), H, dx, H, rinv, dw, M, H, 1e-6, 1, dxb, H + 8, S())
     assert (dx.cpu() - 1.0 - x.grad).abs().max().item() < 1e-5 * max(1.0, x.grad.abs().max().item())
+    assert torch.equal(dxb[:, :H], dx.to(torch.bfloat16)) and (dxb[:, H:] == 0).all()
     assert (dw.cpu() - w.grad).abs().max().item() < 1e-4 * w.grad.abs().max().item()
     dx2 = torch.full((M, H), 1.0, device=dev)                      # no weight gradient, overwrite
-    lib.call("vr2_rmsnorm_bwd", x.detach().to(dev), H, w.detach().to(dev), dy.to(dev), H, dx2, H, None, None, M, H, 1e-6, 0, S())
+    lib.call("vr2_rmsnorm_bwd", x.detach().to(dev), H, w.detach().to(dev), dy.to(dev), H, dx2, H, None, None, M, H, 1e-6, 0, None, 0, S())
     assert (dx2.cpu() - x.grad).abs().max().item() < 1e-5 * max(1.0, x.grad.abs().max().item())
 
 

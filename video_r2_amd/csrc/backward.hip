@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16* __restrict_
 // rinv[m] = inv is also written (the weight-gradient column pass needs it).
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                           const float* __restrict__ dy, long ldy, float* __restrict__ dx, long lddx,
-                                                          float* __restrict__ rinv, int H, float eps, int accumulate) {
+                                                          float* __restrict__ rinv, int H, float eps, int accumulate,
+                                                          bf16* __restrict__ dxb, long lddb) {
   __shared__ float scratch[4];
   const int m = blockIdx.x;
   const float* xr = x + (long)m * ldx;
@@ -82,6 +83,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
       o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
     }
     *reinterpret_cast<float4*>(dxr + i) = o;
+    if (dxb) {
+      bf16x4 ob = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+      *reinterpret_cast<bf16x4*>(dxb + (long)m * lddb + i) = ob;
+    }
   }
 }
 
@@ -93,7 +98,7 @@ template <int NG>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                              const float* __restrict__ dy, long ldy, float* __restrict__ dx, long lddx,
                                                              float* __restrict__ rinv, float* __restrict__ dw, int M, int H, float eps,
-                                                             int accumulate, int rows_per_block) {
+                                                             int accumulate, int rows_per_block, bf16* __restrict__ dxb, long lddb) {
   __shared__ float scratch[8];
   __shared__ __attribute__((aligned(16))) float cols[NG * 1024];
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -143,6 +148,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const float* __rest
         o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
       }
       *reinterpret_cast<float4*>(dxr + i) = o;
+      if (dxb) {   // the bf16 copy the next dgrad / wgrad GEMMs read (saves a separate cast pass over dx)
+        bf16x4 ob = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+        *reinterpret_cast<bf16x4*>(dxb + (long)m * lddb + i) = ob;
+      }
       acc[j].x += dv[j].x * xv[j].x * inv; acc[j].y += dv[j].y * xv[j].y * inv;
       acc[j].z += dv[j].z * xv[j].z * inv; acc[j].w += dv[j].w * xv[j].w * inv;
     }
@@ -260,8 +269,9 @@ extern "C" int vr2_swiglu_fwd(const void* gu_bf16, int64_t ldg, void* act_bf16, 
 
 extern "C" int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32, const void* dy_f32, int64_t ldy, void* dx_f32,
                                int64_t lddx, void* rinv_f32, void* dw_f32, int64_t M, int64_t H, float eps, int accumulate,
-                               void* stream) {
+                               void* dx_bf16, int64_t lddb, void* stream) {
   VR2_REQUIRE(M >= 1 && H % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && lddx % 4 == 0, "vr2_rmsnorm_bwd: bad shape");
+  VR2_REQUIRE(dx_bf16 == nullptr || (lddb % 4 == 0 && lddb >= H), "vr2_rmsnorm_bwd: bad bf16 output stride");
   VR2_REQUIRE(dw_f32 == nullptr || rinv_f32 != nullptr, "vr2_rmsnorm_bwd: dw needs the rinv scratch");
   if (dw_f32 && H <= 4096) {   // one pass: rows and the weight gradient
     const int rpb = M >= 4096 ? 8 : (M >= 1024 ? 4 : 1);
@@ -269,16 +279,16 @@ extern "C" int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32
     if (H <= 2048)
       hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel<2>, dim3(nb), dim3(256), 0, STREAM, (const float*)x_f32, (long)ldx, (const float*)w_f32,
                          (const float*)dy_f32, (long)ldy, (float*)dx_f32, (long)lddx, (float*)rinv_f32, (float*)dw_f32, (int)M, (int)H, eps,
-                         accumulate, rpb);
+                         accumulate, rpb, (bf16*)dx_bf16, (long)lddb);
     else
       hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel<4>, dim3(nb), dim3(256), 0, STREAM, (const float*)x_f32, (long)ldx, (const float*)w_f32,
                          (const float*)dy_f32, (long)ldy, (float*)dx_f32, (long)lddx, (float*)rinv_f32, (float*)dw_f32, (int)M, (int)H, eps,
-                         accumulate, rpb);
+                         accumulate, rpb, (bf16*)dx_bf16, (long)lddb);
     return vr2_check_launch("vr2_rmsnorm_bwd(rows + dw)");
   }
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((unsigned)M), dim3(256), 0, STREAM, (const float*)x_f32, (long)ldx,
                      (const float*)w_f32, (const float*)dy_f32, (long)ldy, (float*)dx_f32, (long)lddx, (float*)rinv_f32, (int)H, eps,
-                     accumulate);
+                     accumulate, (bf16*)dx_bf16, (long)lddb);
   if (vr2_check_launch("vr2_rmsnorm_bwd")) return -2;
   if (dw_f32) {
     const int rpb = 256;

@@ -261,7 +261,7 @@ class Trainer:
             self._wgrad(dz, s["hn"][r0:r0 + n], "lm_head", V, H, n)
         dhs = b("t.dhs", (R, H), torch.float32)
         rinv = b("t.rinv", (max(T, R),), torch.float32)
-        lib.call("vr2_rmsnorm_bwd", s["hs"], H, W["norm"], dhn, H, dhs, H, rinv, st.grad["norm"], R, H, t.rms_norm_eps, 0, eng.s)
+        lib.call("vr2_rmsnorm_bwd", s["hs"], H, W["norm"], dhn, H, dhs, H, rinv, st.grad["norm"], R, H, t.rms_norm_eps, 0, None, 0, eng.s)
         if exchange:
             self._exchange("head")
         dx = b("t.dx", (T, H), torch.float32)
@@ -280,9 +280,9 @@ class Trainer:
         dvv = b("t.dv32", (T, nkv * hd), torch.float32)
         dqkv = b("t.dqkv", (T, nqkv), torch.bfloat16)
         scale = hd ** -0.5
+        self._cast(dx, dxb, T, H)          # after this, every update of dx (rmsnorm_bwd) also refreshes its bf16 copy dxb
         for l in reversed(range(L)):
             # ---- MLP
-            self._cast(dx, dxb, T, H)
             self._gemm(dxb, f"l{l}.down_w_t", None, dact, T, EPI_BF16)
             gu = sv["gu"][l]
             self._wgrad(dxb, sv["act"][l], f"l{l}.down_w", H, I16, T)
@@ -290,9 +290,8 @@ class Trainer:
             self._gemm(dgu, f"l{l}.gu_w_t", None, dxn, T, EPI_F32)
             self._wgrad(dgu, sv["xn2"][l], f"l{l}.gu_w", 2 * I16, H, T)
             lib.call("vr2_rmsnorm_bwd", sv["x_mid"][l], H, W[f"l{l}.ln2"], dxn, H, dx, H, rinv, st.grad[f"l{l}.ln2"], T, H,
-                     t.rms_norm_eps, 1, eng.s)
+                     t.rms_norm_eps, 1, dxb, dxb.stride(0), eng.s)
             # ---- attention
-            self._cast(dx, dxb, T, H)
             self._gemm(dxb, f"l{l}.o_w_t", None, datt, T, EPI_BF16)
             att, q, k, v, lse = sv["att"][l], sv["q"][l], sv["k"][l], sv["v"][l], sv["lse"][l]
             self._wgrad(dxb, att, f"l{l}.o_w", H, nq * hd, T)
@@ -307,7 +306,7 @@ class Trainer:
             self._gemm(dqkv, f"l{l}.qkv_w_t", None, dxn, T, EPI_F32)
             self._wgrad(dqkv, sv["xn1"][l], f"l{l}.qkv_w", nqkv, H, T)
             lib.call("vr2_rmsnorm_bwd", sv["x_in"][l], H, W[f"l{l}.ln1"], dxn, H, dx, H, rinv, st.grad[f"l{l}.ln1"], T, H,
-                     t.rms_norm_eps, 1, eng.s)
+                     t.rms_norm_eps, 1, dxb, dxb.stride(0), eng.s)
             if exchange:
                 self._exchange(l)
         # ---- embedding rows (video placeholder rows carry frozen vision features: no gradient)

@@ -523,6 +523,8 @@ def main():
                        "parallelism": f"dp{world} (prompt groups sharded; one gradient all-reduce per step)"},
             "last_loss": loss,
             "hbm_peak_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),   # torch allocator high-water mark on rank 0
+            "hbm_reserved_GB": round(torch.cuda.max_memory_reserved() / 1e9, 1),  # ... incl. the allocator's cached blocks
+            "hbm_free_GB": round(torch.cuda.mem_get_info()[0] / 1e9, 1),          # what the driver still reports free at the end
         }
         if recipe is not None:
             line["recipe_shape_samples_per_s"] = G * world / recipe        # 1 group per GPU per step, full step, one sample of it

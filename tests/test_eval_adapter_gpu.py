@@ -70,6 +70,10 @@ def test_generate_until_matches_direct_decode_and_keeps_order(tmp_path):
         ev.generate_until([Req("q", {}, lambda d: [object()], 0, "videomme", "test")])
     with pytest.raises(NotImplementedError):
         ev.loglikelihood([])
+    # batch_size 2: the requests share one vision pass, one prefill and one decode; greedy answers are the ones of batch_size 1
+    ev2 = VideoR2EvalModel(model=m, tokenizer=tok, task_dict=docs, max_num_frames=6, min_pixels=4704, max_pixels=4704,
+                           reasoning_prompt="\\nThink first.", batch_size=2)
+    assert ev2.generate_until(reqs) == out
     # sampling path runs and honours the seed
     s1 = ev.generate_until([Req("q", {"temperature": 0.8, "max_new_tokens": 6, "seed": 5}, vis, 0, "videomme", "test")])
     s2 = ev.generate_until([Req("q", {"temperature": 0.8, "max_new_tokens": 6, "seed": 5}, vis, 0, "videomme", "test")])

@@ -114,8 +114,9 @@ class VideoR2EvalModel:
         frames = torch.from_numpy(fr).permute(0, 3, 1, 2).contiguous()
         return frames, sfps, dims
 
-    def _answer(self, context, visuals, gen_kwargs):
-        cfg, eng = self._model.cfg, self._model.engine
+    def _prepare(self, context, visuals):
+        """one request -> (prompt ids, clips for Engine.encode_videos, second_per_grid_ts, the context as sent)"""
+        cfg = self._model.cfg
         context = context.replace("<image>", "")
         if self.reasoning_prompt:
             context = context.strip() + self.reasoning_prompt
@@ -139,29 +140,50 @@ class VideoR2EvalModel:
             ids.extend(self._tokenizer.encode(piece))
             if k < len(clips):
                 ids.extend([cfg.video_token_id] * counts[k])
-        ids = np.asarray(ids, dtype=np.int64)
+        return np.asarray(ids, dtype=np.int64), clips, secs or None, context
+
+    def _answers(self, prepared, gen_kwargs):
+        """the requests of one batch (same generation arguments): ONE pass of the vision tower over all their clips, ONE prompt
+        prefill, and their sequences decoded together (the decode is weight-streaming bound: b rows cost little more than one)"""
+        cfg, eng = self._model.cfg, self._model.engine
         kw = {"max_new_tokens": 128, "temperature": 0.0, "top_p": None, "num_beams": 1, **gen_kwargs}
         if (kw.get("num_beams") or 1) != 1:
             raise ValueError(f"num_beams={kw['num_beams']}: the engine samples or decodes greedily, it has no beam search")
         sample = float(kw["temperature"] or 0.0) > 0.0
         if sample and kw.get("top_p") not in (None, 1.0):
             raise ValueError(f"top_p={kw['top_p']}: the engine's sampler implements temperature + top-k only")
-        (emb, plan), = eng.encode_videos(clips, per_prompt=[len(clips)]) if clips else [(None, None)]
-        st = eng.prefill(self._model.text, ids, None if emb is None else emb.clone(), plan, secs or None, tag="pol")
-        toks, _ = eng.decode(self._model.text, st, 1, int(kw["max_new_tokens"]), temperature=float(kw["temperature"]) if sample else 1.0,
-                             top_k=int(kw.get("top_k") or 50) if sample else 1, seed=int(kw.get("seed", 0)), eos_token_id=cfg.eos_token_id)
+        idss = [p[0] for p in prepared]
+        clips = [p[1] for p in prepared]
+        enc = eng.encode_videos([c for cl in clips for c in cl], per_prompt=[len(cl) for cl in clips])
+        dec = dict(temperature=float(kw["temperature"]) if sample else 1.0, top_k=int(kw.get("top_k") or 50) if sample else 1,
+                   seed=int(kw.get("seed", 0)), eos_token_id=cfg.eos_token_id)
+        if len(prepared) == 1:
+            emb, plan = enc[0]
+            st = eng.prefill(self._model.text, idss[0], None if emb is None else emb.clone(), plan, prepared[0][2], tag="pol")
+            toks, _ = eng.decode(self._model.text, st, 1, int(kw["max_new_tokens"]), **dec)
+        else:
+            slots = eng.prefix_slots(len(prepared), max(len(i) for i in idss), tag="pol")
+            states = eng.prefill_batch(self._model.text, [(ids, emb, plan, p[2]) for ids, (emb, plan), p in zip(idss, enc, prepared)],
+                                       slots, tag="pol")
+            toks, _ = eng.decode(self._model.text, states, 1, int(kw["max_new_tokens"]), **dec)
         eng.sync()
-        row = toks[0].cpu().numpy()
-        stop = np.flatnonzero(row == cfg.eos_token_id)
-        row = row[:stop[0]] if stop.size else row
-        return self._tokenizer.decode(row.tolist(), skip_special_tokens=True), context
+        out = []
+        for row in toks.cpu().numpy():
+            stop = np.flatnonzero(row == cfg.eos_token_id)
+            row = row[:stop[0]] if stop.size else row
+            out.append(self._tokenizer.decode(row.tolist(), skip_special_tokens=True))
+        return out
 
     def generate_until(self, requests):
-        """-> list[str], one answer per request, in request order."""
-        out = []
-        for req in requests:
-            context, gen_kwargs, doc_to_visual, doc_id, task, split = req.args
-            visuals = doc_to_visual(self.task_dict[task][split][doc_id])
+        """-> list[str], one answer per request, in request order.  Consecutive requests with the same generation arguments are
+        answered batch_size at a time."""
+        out = [None] * len(requests)
+        i = 0
+        while i < len(requests):
+            gen_kwargs = requests[i].args[1]
+            j = i
+            while j < len(requests) and j - i < self.batch_size_per_gpu and requests[j].args[1] == gen_kwargs:
+                j += 1
             until = gen_kwargs.get("until", [self._tokenizer.decode([self.eot_token_id], skip_special_tokens=False)])
             if isinstance(until, str):
                 until = [until]
@@ -169,14 +191,19 @@ class VideoR2EvalModel:
                 raise ValueError(f"Expected `gen_kwargs['until']` to be of type Union[str, list], but got {type(until)}")
             until = [u for u in until if u != "\n\n"]
             kw = {k: v for k, v in gen_kwargs.items() if k != "until"}
-            ans, used_context = self._answer(context, list(visuals), kw)
-            for term in until:
-                if len(term) > 0:
-                    ans = ans.split(term)[0]
-            out.append(ans)
-            hook = getattr(self, "cache_hook", None)
-            if hook is not None:
-                hook.add_partial("generate_until", (used_context, gen_kwargs), ans)
+            prepared = []
+            for req in requests[i:j]:
+                context, _, doc_to_visual, doc_id, task, split = req.args
+                prepared.append(self._prepare(context, list(doc_to_visual(self.task_dict[task][split][doc_id]))))
+            for k, ans in enumerate(self._answers(prepared, kw)):
+                for term in until:
+                    if len(term) > 0:
+                        ans = ans.split(term)[0]
+                out[i + k] = ans
+                hook = getattr(self, "cache_hook", None)
+                if hook is not None:
+                    hook.add_partial("generate_until", (prepared[k][3], gen_kwargs), ans)
+            i = j
         return out
 
 

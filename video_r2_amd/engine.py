@@ -581,17 +581,17 @@ class Engine:
         lib.call("vr2_add_int", bufs["step"], 1, self.s)
 
     def _prefix_chunk(self, n_groups, n_prompt):
-        """Prompt keys per shared-prefix attention workgroup: the largest of 256 / 128 / 64 that still gives the chip >= 256
-        workgroups (groups x KV heads x chunks); long chunks amortise the per-workgroup latency (K/V tiles are loaded one tile
-        ahead), short ones are needed when few groups decode together.  Measured at 16 groups, S = 1088: 22.7 / 19.1 / 17.6 us
-        per layer for 64 / 128 / 256."""
+        """Prompt keys per shared-prefix attention workgroup: the shortest multiple of 64 that covers the prompt with at most ONE
+        workgroup per CU (groups x KV heads x chunks <= 256), between 64 and 512.  The workgroups are latency-bound walks over
+        their 64-key tiles, so a second round on some CUs costs more than slightly longer walks on all of them.  Measured at
+        16 groups, S = 1088 (the launch at a 32-token suffix, profiles/r02_kernel_stats_default_bench_p16.md): 17.8 / 18.7 /
+        17.0 / 23.0 us for 192 / 256 / 320 / 576; 22.7 / 19.1 for 64 / 128 in round 1."""
         if PREFIX_CHUNK:
             return PREFIX_CHUNK
         nkv = self.cfg.text.num_key_value_heads
-        for pc in (256, 128):
-            if n_groups * nkv * ((n_prompt + pc - 1) // pc) >= 256:
-                return pc
-        return 64
+        per = max(1, 256 // max(1, n_groups * nkv))               # chunks one (group, KV head) may have
+        pc = -(-(-(-n_prompt // per)) // 64) * 64                  # ceil(ceil(S / per) / 64) * 64
+        return min(512, max(64, pc))
 
     def _suffix_chunk(self, n_seqs):
         """Own-suffix keys per decode-attention workgroup (one wave, 32-key tiles loaded one ahead): 256 once sequences x KV

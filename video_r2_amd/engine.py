@@ -593,19 +593,22 @@ class Engine:
         pc = -(-(-(-n_prompt // per)) // 64) * 64                  # ceil(ceil(S / per) / 64) * 64
         return min(512, max(64, pc))
 
-    def _suffix_chunk(self, n_seqs):
-        """Own-suffix keys per decode-attention workgroup (one wave, 32-key tiles loaded one ahead): 256 once sequences x KV
-        heads alone fill the chip, shorter chunks for more workgroups otherwise (measured at 128 sequences, C = 1024:
-        41.3 / 42.7 / 38.7 us per layer and 8.4 / 7.4 / 6.7 us in the combine for 64 / 128 / 256)."""
+    def _suffix_chunk(self, n_seqs, n_new):
+        """Own-suffix keys per decode-attention wave (four waves per workgroup): the shortest multiple of 64 that covers the
+        n_new generated tokens with at most one suffix workgroup per CU (sequences x KV heads x chunks <= 1024 waves), between 64
+        and 1024 -- the same rule as _prefix_chunk.  Measured at 128 sequences, C = 1024, the whole launch per layer: 51.2 /
+        42.8 / 42.1 / 40.6 / 43.7 / 46.1 us for 128 / 256 / 384 / 512 / 768 / 1024 keys; at 64 sequences 256 was the round-1
+        optimum, at 8 sequences 64."""
         if DECODE_CHUNK:
             return DECODE_CHUNK
-        wgs = n_seqs * self.cfg.text.num_key_value_heads
-        return 256 if wgs >= 256 else 128 if wgs >= 128 else 64
+        per = max(1, 1024 // max(1, n_seqs * self.cfg.text.num_key_value_heads))   # chunks one (sequence, KV head) may have
+        sc = -(-(-(-n_new // per)) // 64) * 64
+        return min(1024, max(64, sc))
 
     def _decode_bufs(self, G, C, n_prompt, pchunk=64):
         t = self.cfg.text
         H, hd, nq, nkv, I, V, L = t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size, t.vocab_size, t.num_hidden_layers
-        schunk = self._suffix_chunk(G)
+        schunk = self._suffix_chunk(G, C)
         npc, nsc = (n_prompt + pchunk - 1) // pchunk, (C + schunk - 1) // schunk
         nchunk = npc + nsc
         # grid-level split-K per projection (profiles/src/tune_gemv.py on MI355X): enough workgroups to cover 256 CUs

@@ -21,7 +21,7 @@ o = torch.zeros_like(q); lse = torch.zeros(T, nH, device=dev)
 work = np.concatenate([vp.causal_work(S_, 0, 0, 0, 0)] + [vp.causal_work(C, S_ + i * C, 0, S_, S_ + i * C) for i in range(G)])
 dwork = torch.from_numpy(work).to(dev)
 wq = np.concatenate([vp.causal_work(S_, 0, 0, 0, 0, q_tile=128)] + [vp.causal_work(C, S_ + i * C, 0, S_, S_ + i * C, q_tile=128) for i in range(G)])
-dwq = torch.from_numpy(wq).to(dev)
+dwq = torch.from_numpy(np.ascontiguousarray(vp.heaviest_first(wq) if len(sys.argv) <= 4 else wq)).to(dev)
 rowc = torch.zeros(2, nH, T, device=dev)
 dq = torch.zeros_like(q); dk = torch.zeros(T, nKV * hd, device=dev); dv = torch.zeros_like(dk)
 pairs = S_ * (S_ + 1) / 2 + G * (C * S_ + C * (C + 1) / 2)

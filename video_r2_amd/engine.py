@@ -770,7 +770,7 @@ class Engine:
         lib.call("vr2_mrope_table", d_pos, T, self.inv_freq, self.section, cos, sin, hd, self.s)
         ks = self.buf(tag + ".sk", (T, nkv * hd), torch.bfloat16)
         vs = self.buf(tag + ".sv", (T, nkv * hd), torch.bfloat16)
-        work = np.concatenate([vp.causal_work(C, g * C, 0, S, g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0)
+        work = vp.heaviest_first(np.concatenate([vp.causal_work(C, g * C, 0, S, g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0))
         d_work = _i32(work, self.device)
         self._lm_rows(W, x, T, cos, sin, d_work, st.prefix_k, st.prefix_v, ks, vs, 0, tag + ".s")
         # shift: hs[(g,0)] = prompt last hidden ; hs[(g,j)] = x[(g,j-1)]

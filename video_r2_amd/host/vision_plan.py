@@ -80,6 +80,14 @@ def causal_work(n_q, q_row0, prefix_row0, prefix_len, self_row0, q_tile=Q_TILE, 
     return np.asarray(items, dtype=np.int32).reshape(-1, 8)
 
 
+def heaviest_first(work):
+    """Attention work items (rows of causal_work / segment_work) in descending order of the keys they walk: the grid is
+    dispatched in order, so the long items start first and the short ones fill the tail."""
+    w = np.asarray(work)
+    keys = w[:, 3].astype(np.int64) + np.minimum(w[:, 5].astype(np.int64), w[:, 6].astype(np.int64) + w[:, 1].astype(np.int64))
+    return w[np.argsort(-keys, kind="stable")]
+
+
 def key_work(n_prompt, n_seq, n_comp, k_tile=128, q_split=512, group=1, max_steps=64):
     """Key-centric work items (vr2_attn_bwd_dkv) for the unified row space [prompt rows | seq 0 rows | seq 1 rows | ...]:
     a prompt key tile (k_tile <= 128 rows) is seen by the prompt rows from its first row on (causal) and by EVERY completion

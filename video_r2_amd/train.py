@@ -166,8 +166,8 @@ class Trainer:
             lib.call("vr2_scatter_rows_f32", video_embeds, video_embeds.stride(0), dst, x, x.stride(0), vid_pos.shape[0], H, eng.s)
         cos = b("t.cos", (T, hd // 2), torch.float32); sin = b("t.sin", (T, hd // 2), torch.float32)
         lib.call("vr2_mrope_table", _i32(pos_all, eng.device), T, eng.inv_freq, eng.section, cos, sin, hd, eng.s)
-        work = np.concatenate([vp.causal_work(S, 0, 0, 0, 0, q_tile=vp.LM_Q_TILE)] +
-                              [vp.causal_work(C, S + g * C, 0, S, S + g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0)
+        work = vp.heaviest_first(np.concatenate([vp.causal_work(S, 0, 0, 0, 0, q_tile=vp.LM_Q_TILE)] +
+                                                [vp.causal_work(C, S + g * C, 0, S, S + g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0))
         d_work = _i32(work, eng.device)
         kwork = _i32(vp.key_work(S, G, C, group=t.group), eng.device)
         sv = dict(x_in=b("t.x_in", (L, T, H), torch.float32), xn1=b("t.xn1", (L, T, H), torch.bfloat16),

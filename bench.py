@@ -54,7 +54,12 @@ def parse():
     p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8", "fp8w"],
                    help="fp8 (BASELINE config 5): the decode GEMVs stream per-channel e4m3 copies of the LM weights and, above 16 "
                         "rows, per-row e4m3 activations on the fp8 MFMA; fp8w: weight-only (bf16 activations, bf16 MFMA: round 1). "
-                        "Prefill, scoring and training stay bf16; the copies are re-quantised after every optimiser step (timed)")
+                        "With fp8 the no-grad LM GEMMs (rollout prefill, reference prefill + log-probs) run on the same copies with fp8 "
+                        "activations too (vr2_gemm_a8w8); the training forward / backward stay bf16; the policy's copies are "
+                        "re-quantised after every optimiser step (timed)")
+    p.add_argument("--no-gemm-fp8", action="store_true",
+                   help="with --decode-weights fp8: keep the no-grad LM GEMMs (rollout prefill, reference prefill + log-probs) on the "
+                        "bf16 path instead of per-row e4m3 activations x e4m3 weights on the block-scaled fp8 MFMA (A/B switch)")
     p.add_argument("--launch-check", action="store_true",
                    help="rehearse the N-rank launch only: process group, barrier, max-over-ranks timing and the JSON line, no "
                         "engine work (runs without a GPU; tests/test_bench_launch.py)")
@@ -246,6 +251,9 @@ def main():
         W.add_fp8_decode_copies(pol)
         eng.decode_fp8 = True
         eng.decode_fp8_act = a.decode_weights == "fp8"
+        if a.decode_weights == "fp8" and not a.no_gemm_fp8:
+            W.add_fp8_decode_copies(ref)                           # frozen: quantised once
+            eng.gemm_fp8 = True
     from video_r2_amd.train import Trainer
     upd = None if a.no_update else Trainer(eng, pol)       # fp32 masters + Adam moments + transposed packed copies
     P = a.prompts_per_gpu
@@ -512,7 +520,8 @@ def main():
             "rccl_ranks": world if (world > 1 and backend == "nccl") else 0, "dist_backend": backend if world > 1 else None,
             "rank_ms_per_step": [t / a.steps * 1e3 for t in rank_dt],
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not fp8 else ("bf16 (decode: fp8 e4m3 weights per channel x fp8 activations per row on the fp8 MFMA)" if a.decode_weights == "fp8"
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not fp8 else (("bf16 training; decode, rollout prefill and reference scoring: fp8 e4m3 weights per channel x fp8 activations per row on the fp8 MFMA" if eng.gemm_fp8
+                                                                             else "bf16 (decode: fp8 e4m3 weights per channel x fp8 activations per row on the fp8 MFMA)") if a.decode_weights == "fp8"
                                                                             else "bf16 (decode weights fp8 e4m3, per-channel scales)"), "data": "synthetic",
             "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} {a.frames} frames 224^2, G={G}, {C} new tokens, {P} prompt group(s) per GPU per step",
                        "prompts_per_gpu_per_step": P,

@@ -72,6 +72,12 @@ int vr2_gemv_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64
                   int64_t N, int64_t K, void* out_f32, int64_t split_stride, int64_t ldo, int nsplit, void* stream);
 int vr2_gemv_gateup_silu_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64_t M, const void* W_packed_fp8,
                               const void* wscale_f32, int64_t I, int64_t K, void* act_bf16, int64_t ldo, void* stream);
+/* The same operands at prefill / scoring row counts (config 5, the no-grad passes: rollout prefill, reference prefill +
+ * log-probs -- the nn.Linear calls vr2_gemm_bf16 replaces, with quantised operands): C (op)= (q_x q_w^T) * scale_x[m] * scale_w[n]
+ * + bias, epilogues VR2_EPI_BF16 / _F32 / _ADD_F32 / _SWIGLU_BF16.  Tilings, staging and LDS images of vr2_gemm_bf16 on half the
+ * bytes per k; the multiply is v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (2x the bf16 MFMA rate).  K % 128 == 0. */
+int vr2_gemm_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, const void* W_packed_fp8, const void* wscale_f32,
+                  const void* bias_f32, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, void* stream);
 
 /* ---- row kernels ------------------------------------------------------------------------------------------- */
 /* x (+)= bias + sum_s partial[s] ; y = bf16(rmsnorm(x) * w).  Qwen2_5_VLRMSNorm HF:65-79 (K2, K10) fused with the

@@ -427,6 +427,71 @@ def test_fp8_decode_weights_vs_oracle_with_dequantised_weights(golden_dir):
     assert 1e-4 < qerr < 0.2, qerr                               # the quantised model differs measurably, but at the e4m3 level
 
 
+def test_fp8_gemm_prefill_and_scoring_vs_quantised_oracle(golden_dir):
+    """BASELINE config 5, the no-grad LM passes (Engine.gemm_fp8): prompt prefill and teacher-forced scoring run every LM
+    projection and the lm_head as vr2_gemm_a8w8 -- per-row e4m3 activations x per-channel e4m3 weights on the block-scaled fp8
+    MFMA.  Per-token log-probs against the fp32 oracle run with the DEQUANTISED weights and quantise-dequantised projection
+    inputs.  As for the decode test above an exact match is not available end to end (the engine quantises ITS bf16 activations;
+    a few per cent of the e4m3 codes land on the other side of a rounding boundary), so the bar is the size of the quantisation
+    effect itself: the kernel-vs-quantised-oracle distance must stay below the quantised-vs-bf16 model distance (measured: 0.65 of
+    it; a wiring slip -- a wrong scale, a tensor quantised twice or not at all -- is O(1), many times that), and the fp8 pass must
+    really differ from the bf16 pass by about that distance (the mode is applied).  The GEMM itself is checked exactly in
+    tests/test_kernels_gpu.py::test_gemm_fp8_operands_on_the_scaled_mfma."""
+    from video_r2_amd import weights as W
+    f = _load(golden_dir, "gen_tiny_g2")
+    ocfg = om.cfg_tiny(2)
+    eng, w, cfg = make_engine(ocfg, int(f["seed"]))
+    W.add_fp8_decode_copies(eng.text)
+    w8 = dict(w)
+    for k in [k for k in w if k.startswith("model.layers.") and k.endswith("_proj.weight")] + ["lm_head.weight"]:
+        q, s = W.quantize_rows_fp8(w[k])
+        w8[k] = W.dequantize_rows_fp8(q, s)
+    G = int(f["G"])
+    prompt = f["input_ids"][0]
+    comp = f["sequences"][:, prompt.shape[0]:]
+    C = comp.shape[1]
+    S = len(prompt)
+    px, grid = pixels_from_frames(f["frames_u8"], cfg.vision)
+    emb, plan = eng.encode_video(torch.from_numpy(px).to(eng.device), [grid])
+    full = np.concatenate([np.repeat(prompt[None], G, 0), comp], 1)
+    mm = _group_mm(px, grid, G)
+    with torch.no_grad():
+        vemb = om.vision_forward(w, ocfg, mm["pixel_values_videos"], mm["video_grid_thw"])      # the vision tower stays bf16
+        emb_all = om.build_inputs_embeds(w, ocfg, torch.from_numpy(full), vemb)
+        pos, _ = ovi.rope_index(full, np.ones_like(full), mm["video_grid_thw"], mm["second_per_grid_ts"],
+                                video_token_id=ocfg.video_token_id, image_token_id=ocfg.image_token_id,
+                                merge_size=ocfg.vision.spatial_merge_size, tokens_per_second=ocfg.vision.tokens_per_second)
+
+        def logps(wts, aq):
+            h = om.lm_forward(wts, ocfg, emb_all, torch.from_numpy(pos), None, None, act_quant=aq)
+            h = h if aq is None else aq(h)
+            lg = (h[:, S - 1:S + C - 1] @ om.lm_head_weight(wts, ocfg).t()) / 0.9
+            return torch.log_softmax(lg, -1).gather(2, torch.from_numpy(comp.astype(np.int64))[..., None])[..., 0].numpy()
+        want_q = logps(w8, om.fp8_qdq_rows)
+        want_b = logps(w, None)
+    st = eng.prefill(eng.text, prompt, emb, plan, [1.0])
+    lp_b = eng.score(eng.text, st, comp, 0.9).cpu().numpy().copy()
+    eng.gemm_fp8 = True
+    try:
+        st8 = eng.prefill(eng.text, prompt, emb, plan, [1.0])
+        lp_q = eng.score(eng.text, st8, comp, 0.9).cpu().numpy().copy()
+        # the batched prefill takes the same path (two copies of the prompt in one row space)
+        slots = eng.prefix_slots(2, S)
+        sts = eng.prefill_batch(eng.text, [(prompt, emb, plan, [1.0])] * 2, slots)
+        lp_q2 = eng.score(eng.text, sts[1], comp, 0.9).cpu().numpy().copy()
+    finally:
+        eng.gemm_fp8 = False
+    eng.sync()
+    assert rel_err(lp_b, want_b).max() < LOGP_TOL                              # (the bf16 pass is untouched by the copies)
+    e_model = np.abs(want_q - want_b).mean()                                     # what config 5's quantisation costs, per token
+    e_kernel = np.abs(lp_q - want_q).mean()
+    moved = np.abs(lp_q - lp_b).mean()
+    print("fp8 GEMMs: mean |dlogp| kernel vs quantised oracle %.3e; quantised vs bf16 model %.3e; engine fp8 vs bf16 %.3e" % (e_kernel, e_model, moved))
+    assert e_kernel < e_model and e_kernel < 0.1, (e_kernel, e_model)
+    assert 0.5 * e_model < moved < 2 * e_model, (moved, e_model)
+    assert np.abs(lp_q2 - lp_q).mean() < e_model                                # batched == single up to rounding-boundary flips
+
+
 def test_text_only_prompt_logps_vs_oracle():
     """a prompt without any video (the reference's dataset also carries text-only rows): no vision tower, 1-D rope positions;
     scoring and the decode path against the fp32 oracle"""

@@ -658,3 +658,61 @@ def test_add_rmsnorm_with_fused_fp8_quantisation(dev):
     torch.cuda.synchronize()
     assert torch.equal(xa, xb) and torch.equal(ya, yb) and torch.equal(sa, sb)
     assert torch.equal(qa, qb[:, :H]) and bool((qb[:, H:] == 7).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(40, 424, 1152),        # 64-row tiles, ragged N
+                                   (1088, 4608, 3584),     # 128-row tiles (prefill of one prompt)
+                                   (2304, 4608, 1152),     # 256-row tiles, one workgroup per CU
+                                   (2368, 3584, 2048)])    # 256-row main + 64 tail rows as k-parts (atomic adds)
+def test_gemm_fp8_operands_on_the_scaled_mfma(dev, M, N, K):
+    """vr2_gemm_a8w8 (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales): per-row e4m3 activations x per-channel e4m3 weights
+    against the float64 matmul of the DEQUANTISED operands -- products of two e4m3 values are exact in fp32, only the summation
+    order differs -- for every tiling the launcher picks and the F32 / ADD_F32 / BF16 / SwiGLU epilogues; plus an exact-integer
+    case where every sum is exact (any fragment-order mistake between the two operands is a hard mismatch)"""
+    from video_r2_amd.weights import dequantize_rows_fp8, interleave_gate_up, pack_tiles_fp8, quantize_rows_fp8
+    g = torch.Generator().manual_seed(7 * M + N)
+    W = torch.randn(N, K, generator=g) * 0.05 * torch.logspace(-1, 1, N)[:, None]
+    x = (2 * torch.randn(M, K, generator=g) * torch.logspace(-1, 1, M)[:, None]).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    qw, sw = quantize_rows_fp8(W)
+    Wd = dequantize_rows_fp8(qw, sw).double()
+    ldq = K + 128                                                          # a row stride above K
+    q8 = torch.zeros((M, ldq), dtype=torch.uint8, device=dev)
+    xs = torch.zeros(M, device=dev)
+    lib.call("vr2_quant_rows_fp8", x.to(dev), K, M, K, q8, ldq, xs, S())
+    xd = (_deinterleave_fp8_rows(q8[:, :K].cpu(), K).view(torch.float8_e4m3fn).float() * xs.cpu()[:, None]).double()
+    Wp, swd = pack_tiles_fp8(qw.to(dev)), torch.cat([sw, torch.ones((-N) % 16)]).to(dev)
+    want = xd @ Wd.t() + bias.double()
+    tol = 5e-5 * want.abs().max()
+    out = torch.full((M, N), 3.0, device=dev)
+    lib.call("vr2_gemm_a8w8", q8, ldq, xs, Wp, swd, bias.to(dev), out, N, M, N, K, 1, S())        # F32
+    assert (out.cpu().double() - want).abs().max() <= tol, (out.cpu().double() - want).abs().max()
+    res = torch.randn(M, N, generator=g)
+    out2 = res.clone().to(dev)
+    lib.call("vr2_gemm_a8w8", q8, ldq, xs, Wp, swd, bias.to(dev), out2, N, M, N, K, 2, S())       # ADD_F32
+    assert (out2.cpu().double() - (want + res.double())).abs().max() <= tol
+    out3 = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    lib.call("vr2_gemm_a8w8", q8, ldq, xs, Wp, swd, None, out3, N, M, N, K, 0, S())               # BF16, no bias
+    w3 = (xd @ Wd.t())
+    assert rel_err(out3.float().cpu().numpy(), w3.numpy(), floor=w3.abs().max().item() * 1e-2).max() < 1e-2
+    # gate/up + SiLU*mul on interleaved weight rows
+    I = (N // 2) // 16 * 16
+    Wg, Wu = W[:I], W[I:2 * I]
+    qg, sg = quantize_rows_fp8(Wg)
+    qu, su = quantize_rows_fp8(Wu)
+    qi, si = interleave_gate_up(qg.to(dev), qu.to(dev)), interleave_gate_up(sg.to(dev), su.to(dev)).contiguous()
+    act = torch.zeros(M, I, dtype=torch.bfloat16, device=dev)
+    lib.call("vr2_gemm_a8w8", q8, ldq, xs, pack_tiles_fp8(qi), si, None, act, I, M, 2 * I, K, 4, S())
+    gd, ud = xd @ dequantize_rows_fp8(qg, sg).double().t(), xd @ dequantize_rows_fp8(qu, su).double().t()
+    wa = torch.nn.functional.silu(gd) * ud
+    assert rel_err(act.float().cpu().numpy(), wa.numpy(), floor=wa.abs().max().item() * 1e-2).max() < 1e-2
+    # exact integers
+    Wi = torch.randint(-8, 9, (N, K), generator=g).float() * 0.25
+    xi = torch.randint(-4, 5, (M, K), generator=g).float()
+    xi[:, 0] = 4.0
+    qwi, swi = quantize_rows_fp8(Wi)
+    lib.call("vr2_quant_rows_fp8", xi.to(torch.bfloat16).to(dev), K, M, K, q8, ldq, xs, S())
+    lib.call("vr2_gemm_a8w8", q8, ldq, xs, pack_tiles_fp8(qwi.to(dev)), torch.cat([swi, torch.ones((-N) % 16)]).to(dev), None, out, N, M, N, K, 1, S())
+    xq = (_deinterleave_fp8_rows(q8[:, :K].cpu(), K).view(torch.float8_e4m3fn).float() * xs.cpu()[:, None]).double()
+    wi = xq @ dequantize_rows_fp8(qwi, swi).double().t()
+    assert (out.cpu().double() - wi).abs().max() <= 2e-6 * wi.abs().max()

@@ -14,9 +14,29 @@
 // block, one vmcnt(0) + barrier per k-tile.
 #include "common.h"
 
+//
+// F8 instantiations (BASELINE config 5, the no-grad passes: rollout prefill, reference prefill + scoring): the SAME kernels on
+// e4m3 operands.  Activations = the bytes of vr2_quant_rows_fp8 / vr2_add_rmsnorm_q8 (per-row scale), weights = the 1-KiB
+// 16-row x 64-k fp8 tiles of the decode GEMVs (per-channel scale): a 128-byte row segment is now 128 k instead of 64, a pair of
+// fp8 weight tiles takes the place of a pair of bf16 ones, so every staging address, LDS image and fragment read below is
+// byte-for-byte the bf16 kernel's with K/2 "bf16 columns".  What changes is the multiply: the two 16-byte fragments a lane
+// used for two v_mfma_f32_16x16x32_bf16 (k = 64) are the 32-byte operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 (k = 128,
+// unit block scales) -- the block-scaled form runs fp8 at twice the bf16 rate (MI355X_MICROARCH.md, Matrix cores), the
+// non-scaled fp8 MFMA only at the bf16 rate -- and the epilogue multiplies the fp32 accumulator by scale_w[n] * scale_x[m].
+// Both operands order the k of a 128-block the same way (slot s of each 64-block: k = 8s.., 32 + 8s..), which is all a dot
+// product needs.
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// one block-scaled fp8 MFMA over the 128 k held by the fragment pairs (w0|w1) x (x0|x1); all block scales = 2^0 (e8m0 127)
+__device__ __forceinline__ f32x4 mma_f8(const bf16x8& w0, const bf16x8& w1, const bf16x8& x0, const bf16x8& x1, const f32x4& c) {
+  const i32x8 a = __builtin_shufflevector(__builtin_bit_cast(i32x4, w0), __builtin_bit_cast(i32x4, w1), 0, 1, 2, 3, 4, 5, 6, 7);
+  const i32x8 b = __builtin_shufflevector(__builtin_bit_cast(i32x4, x0), __builtin_bit_cast(i32x4, x1), 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
 
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_ADD_F32 = 2, EPI_GELU_BF16 = 3, EPI_SWIGLU_BF16 = 4 };
 
@@ -29,10 +49,32 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {   // 16 B per l
 // epilogue shared by the tile variants: lane holds D[row n = 4*fq + r][col m = fr] of each 16x16 accumulator; mw / nw are the
 // wave's first output row / column
 // PRELOADED: the accumulators of an EPI_ADD_F32 launch started from the old output values, nothing is read back here
-template <int EPI, int MT, bool ATOMIC = false, bool PRELOADED = false>
+// F8: acc holds sums of e4m3 products; value = acc * wscale[n] * xscale[m] (applied here, before bias / activation)
+template <int EPI, int MT, bool ATOMIC = false, bool PRELOADED = false, bool F8 = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, int n0, int wn, int fr, int fq,
                                          const float* __restrict__ bias, void* __restrict__ Cv, long ldc, int M, int N,
-                                         bf16* __restrict__ aux, long ldaux) {
+                                         bf16* __restrict__ aux, long ldaux, const float* __restrict__ wscale = nullptr,
+                                         const float* __restrict__ xscale = nullptr) {
+  if constexpr (F8) {
+    float xs[MT];
+    float4 ws[4];
+#pragma unroll
+    for (int im = 0; im < MT; ++im) { const int m = mw + im * 16 + fr; xs[im] = m < M ? xscale[m] : 0.f; }
+#pragma unroll
+    for (int in = 0; in < 4; ++in) {
+      const int n = nw + in * 16 + fq * 4;     // (SwiGLU: interleaved-space row, the scales are stored in that order)
+      ws[in] = n < N ? *reinterpret_cast<const float4*>(wscale + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int in = 0; in < 4; ++in) asm volatile("" ::"v"(ws[in].x), "v"(ws[in].y), "v"(ws[in].z), "v"(ws[in].w));
+#pragma unroll
+    for (int in = 0; in < 4; ++in)
+#pragma unroll
+      for (int im = 0; im < MT; ++im) {
+        acc[in][im][0] *= ws[in].x * xs[im]; acc[in][im][1] *= ws[in].y * xs[im];
+        acc[in][im][2] *= ws[in].z * xs[im]; acc[in][im][3] *= ws[in].w * xs[im];
+      }
+  }
   if (EPI == EPI_SWIGLU_BF16) {
     // weight tiles alternate gate / up (weights.py interleave_gate_up): acc[2j] = gate, acc[2j+1] = up of the SAME 16
     // output columns, held by the same lane -> act = silu(gate + bg) * (up + bu), one rounding, no gate/up round trip
@@ -117,10 +159,13 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, in
 // grid would leave CUs with fewer than ~2 workgroups -- prefill at M = S ~ 1k rows, ViT projections with N = 1280)
 // SPLIT: gridDim.z k-parts of a launch with too few output tiles to fill the chip (the < 256 tail rows of a 256-row tiling at
 // N = 3584 are 28 tiles, each walking the whole K: 0.47 ms at K = 37888 on 28 CUs); fp32 outputs only, the parts add atomically
-template <int EPI, int MT, bool SPLIT = false>
+// F8: A / Wp are e4m3 bytes addressed as pairs (lda, K in 2-byte units = half the fp8 counts), see the file header
+template <int EPI, int MT, bool SPLIT = false, bool F8 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ Wp,
                                                    int n_tiles, const float* __restrict__ bias, void* __restrict__ Cv,
-                                                   long ldc, int M, int N, int K, bf16* __restrict__ aux, long ldaux) {
+                                                   long ldc, int M, int N, int K, bf16* __restrict__ aux, long ldaux,
+                                                   const float* __restrict__ wscale = nullptr,
+                                                   const float* __restrict__ xscale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A (BM x 128 B) | W 16K]
   constexpr int BM_ = 32 * MT;
   constexpr int ABYTES = BM_ * 128;           // activation tile bytes per buffer
@@ -188,6 +233,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
 #pragma unroll
       for (int i = 0; i < 4; ++i) glds16(gw[i] + (long)(t + 1) * 1024, nxt + lw[i]);   // two packed k-steps per k-tile
     }
+    if constexpr (F8) {
+      bf16x8 fa[MT][2], fw[4][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i][kk] = *reinterpret_cast<const bf16x8*>(cur + ABYTES + ((wn * 4 + i) * 2 + kk) * 1024 + lane * 16);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i][kk] = *reinterpret_cast<const bf16x8*>(cur + swz(wm * (16 * MT) + i * 16 + fr, kk * 4 + fq));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int in = 0; in < 4; ++in)
+#pragma unroll
+        for (int im = 0; im < MT; ++im) acc[in][im] = mma_f8(fw[in][0], fw[in][1], fa[im][0], fa[im][1], acc[in][im]);
+      __builtin_amdgcn_s_setprio(0);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 fa[MT], fw[4];
@@ -204,11 +265,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
           acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[in], fa[im], acc[in][im], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA of tile t+1 has landed ...
     __syncthreads();                                   // ... for every wave, and tile t is fully consumed
   }
 
-  epilogue<EPI, MT, SPLIT>(acc, m0 + wm * (16 * MT), n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux);
+  epilogue<EPI, MT, SPLIT, false, F8>(acc, m0 + wm * (16 * MT), n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux, wscale, xscale);
 }
 
 __global__ __launch_bounds__(256) void zero_rows_f32_kernel(float* __restrict__ C, long ldc, int N) {
@@ -230,11 +292,12 @@ __global__ __launch_bounds__(256) void zero_rows_f32_kernel(float* __restrict__ 
 // 1199 TFLOP/s on the LM gate/up shape).
 // Measured (profiles/src/gemm_bench.hip, MI355X, bf16, random operands): LM shapes at T = 9280 rows 0.97-1.23 PFLOP/s vs 0.82-0.91
 // for the 128-row tile; ViT qkv / gate-up (M = 4096) 0.95 / 0.88 vs 0.81 / 0.78.
-template <int EPI>
+template <int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ Wp,
                                                       int n_tiles, const float* __restrict__ bias, void* __restrict__ Cv,
                                                       long ldc, int M, int N, int K, bf16* __restrict__ aux, long ldaux,
-                                                      int tiles_m, int tiles_n) {
+                                                      int tiles_m, int tiles_n, const float* __restrict__ wscale = nullptr,
+                                                      const float* __restrict__ xscale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
@@ -283,14 +346,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16* __restrict__ A
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (EPI == EPI_ADD_F32) {
+      if (EPI == EPI_ADD_F32 && !F8) {     // (F8: the accumulator is scaled in the epilogue, the old output is added there)
         const int n = n0 + wn * 64 + i * 16 + fq * 4, m = m0 + wm * 128 + j * 16 + fr;
         if (n < N && m < M) acc[i][j] = *reinterpret_cast<const f32x4*>((const float*)Cv + (long)m * ldc + n);
       }
     }
   // prologue: tile 0 and the W halves of tile 1
   stage_w(0, 0); stage_w(1, 0); stage_x(0, 0); stage_x(1, 0); stage_w(0, 1); stage_w(1, 1);
-  if (EPI == EPI_ADD_F32) {
+  if (EPI == EPI_ADD_F32 && !F8) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -305,10 +368,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16* __restrict__ A
 #define VR2_MMA(N0, M0)                                                                                                       \
   __builtin_amdgcn_s_barrier();                                                                                               \
   __builtin_amdgcn_s_setprio(1);                                                                                              \
+  if constexpr (F8) {          /* hipcc sinks the scaled MFMAs of all four phases below the last barrier of the k-tile   */   \
+                               /* unless their accumulators are pinned on both sides (empty asm volatile, no instruction) */   \
+    _Pragma("unroll") for (int in = N0; in < N0 + 2; ++in)                                                                    \
+      _Pragma("unroll") for (int im = 0; im < 4; ++im) asm volatile("" : "+v"(acc[in][M0 + im]));                             \
+    _Pragma("unroll") for (int in = N0; in < N0 + 2; ++in)                                                                    \
+      _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                                        \
+        acc[in][M0 + im] = mma_f8(Wf[in][0], Wf[in][1], Xs[im][0], Xs[im][1], acc[in][M0 + im]);                             \
+    _Pragma("unroll") for (int in = N0; in < N0 + 2; ++in)                                                                    \
+      _Pragma("unroll") for (int im = 0; im < 4; ++im) asm volatile("" : "+v"(acc[in][M0 + im]));                             \
+  } else {                                                                                                                    \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                                            \
     _Pragma("unroll") for (int in = N0; in < N0 + 2; ++in)                                                                    \
       _Pragma("unroll") for (int im = 0; im < 4; ++im)                                                                        \
         acc[in][M0 + im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[in][kk], Xs[im][kk], acc[in][M0 + im], 0, 0, 0);       \
+  }                                                                                                                           \
   __builtin_amdgcn_s_setprio(0);                                                                                              \
   __builtin_amdgcn_s_barrier()
   for (int T = 0; T < NT; ++T) {
@@ -342,31 +416,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16* __restrict__ A
   }
 #undef VR2_MMA
   if (wm == 0) __builtin_amdgcn_s_barrier();        // pairs with the stagger barrier of waves 4-7
-  epilogue<EPI, 8, false, true>(acc, m0 + wm * 128, n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux);
+  epilogue<EPI, 8, false, !F8, F8>(acc, m0 + wm * 128, n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux, wscale, xscale);
 }
 
-template <int EPI>
+// F8 launches take A / W as byte pointers re-addressed in 2-byte units: lda, K = HALF the fp8 counts (see the file header)
+template <int EPI, bool F8 = false>
 void launch128(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
-               int64_t K, void* stream, void* aux, int64_t ldaux) {
+               int64_t K, void* stream, void* aux, int64_t ldaux, const float* ws = nullptr, const float* xs = nullptr) {
   const long nb = (N + BN - 1) / BN;
   const long big = ((M + 127) / 128) * nb;
   if (big >= 512) {          // >= 2 workgroups per CU with 128-row tiles
     dim3 grid((unsigned)nb, (unsigned)((M + 127) / 128));
-    hipLaunchKernelGGL((gemm_kernel<EPI, 4>), grid, dim3(256), 65536, (hipStream_t)stream, (const bf16*)A, (long)lda,
+    hipLaunchKernelGGL((gemm_kernel<EPI, 4, false, F8>), grid, dim3(256), 65536, (hipStream_t)stream, (const bf16*)A, (long)lda,
                        (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, C, (long)ldc, (int)M, (int)N, (int)K,
-                       (bf16*)aux, (long)ldaux);
+                       (bf16*)aux, (long)ldaux, ws, xs);
   } else {                   // small grid: 64-row tiles double the workgroup count (48 KiB LDS -> 3 per CU)
     dim3 grid((unsigned)nb, (unsigned)((M + 63) / 64));
-    hipLaunchKernelGGL((gemm_kernel<EPI, 2>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16*)A, (long)lda,
+    hipLaunchKernelGGL((gemm_kernel<EPI, 2, false, F8>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16*)A, (long)lda,
                        (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, C, (long)ldc, (int)M, (int)N, (int)K,
-                       (bf16*)aux, (long)ldaux);
+                       (bf16*)aux, (long)ldaux, ws, xs);
   }
 }
 
 // few rows (a tail of <= 128), fp32 output, long K: 64-row tiles with the k-tiles dealt to enough parts to fill the CUs
-template <int EPI>
+template <int EPI, bool F8 = false>
 bool launch_tail_splitk(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
-                        int64_t K, void* stream) {
+                        int64_t K, void* stream, const float* ws = nullptr, const float* xs = nullptr) {
   if constexpr (EPI == EPI_F32 || EPI == EPI_ADD_F32) {
     const long nb = (N + BN - 1) / BN, mb = (M + 63) / 64, kt = K / BK;
     long parts = 256 / (nb * mb);
@@ -375,27 +450,27 @@ bool launch_tail_splitk(const void* A, int64_t lda, const void* W, const void* b
     if (parts < 2) return false;
     if (EPI == EPI_F32) hipLaunchKernelGGL(zero_rows_f32_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, (float*)C, (long)ldc, (int)N);
     dim3 grid((unsigned)nb, (unsigned)mb, (unsigned)parts);
-    hipLaunchKernelGGL((gemm_kernel<EPI, 2, true>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16*)A, (long)lda,
+    hipLaunchKernelGGL((gemm_kernel<EPI, 2, true, F8>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16*)A, (long)lda,
                        (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, C, (long)ldc, (int)M, (int)N, (int)K,
-                       (bf16*)nullptr, 0L);
+                       (bf16*)nullptr, 0L, ws, xs);
     return true;
   } else {
     return false;
   }
 }
 
-template <int EPI>
+template <int EPI, bool F8 = false>
 void launch256(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
-               int64_t K, void* stream, void* aux, int64_t ldaux) {
+               int64_t K, void* stream, void* aux, int64_t ldaux, const float* ws = nullptr, const float* xs = nullptr) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<EPI, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     attr_set = true;
   }
   const long tm = (M + 255) / 256, tn = (N + 255) / 256;
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3((unsigned)(tm * tn)), dim3(512), 131072, (hipStream_t)stream, (const bf16*)A,
+  hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3((unsigned)(tm * tn)), dim3(512), 131072, (hipStream_t)stream, (const bf16*)A,
                      (long)lda, (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, C, (long)ldc, (int)M, (int)N, (int)K,
-                     (bf16*)aux, (long)ldaux, (int)tm, (int)tn);
+                     (bf16*)aux, (long)ldaux, (int)tm, (int)tn, ws, xs);
 }
 
 // efficiency of a 256-row tiling of M x N, in 1/1024: tiles / (rounds * 256) * M / (tm * 256)
@@ -404,9 +479,9 @@ inline long eff256(int64_t M, int64_t N) {
   return t * M * 1024 / (rounds * 256 * tm * 256);
 }
 
-template <int EPI>
+template <int EPI, bool F8 = false>
 int launch(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
-           int64_t K, void* stream, void* aux = nullptr, int64_t ldaux = 0) {
+           int64_t K, void* stream, void* aux = nullptr, int64_t ldaux = 0, const float* ws = nullptr, const float* xs = nullptr) {
   // 256-row tiles (one workgroup per CU) when their last round over the 256 CUs and their last row of tiles are mostly full
   // (efficiency >= 0.75).  Measured crossovers (profiles/src/gemm_bench.hip): LM q/k/v and gate/up at T ~ 9k rows, lm_head chunks,
   // ViT q/k/v and gate/up qualify; N = 1280 and the M ~ 1k prefill projections stay on the 128-row tiles.  When the full M
@@ -416,16 +491,17 @@ int launch(const void* A, int64_t lda, const void* W, const void* bias, void* C,
   const int64_t tail = M % 256, main = M - tail;
   const size_t esz = (EPI == EPI_F32 || EPI == EPI_ADD_F32) ? 4 : 2;
   if (!no256 && eff256(M, N) >= 768) {
-    launch256<EPI>(A, lda, W, bias, C, ldc, M, N, K, stream, aux, ldaux);
+    launch256<EPI, F8>(A, lda, W, bias, C, ldc, M, N, K, stream, aux, ldaux, ws, xs);
   } else if (!no256 && main >= 2048 && tail > 0 && tail <= 128 && eff256(main, N) >= 922) {
-    launch256<EPI>(A, lda, W, bias, C, ldc, main, N, K, stream, aux, ldaux);
-    if (!launch_tail_splitk<EPI>((const bf16*)A + main * lda, lda, W, bias, (char*)C + main * ldc * esz, ldc, tail, N, K, stream))
-      launch128<EPI>((const bf16*)A + main * lda, lda, W, bias, (char*)C + main * ldc * esz, ldc, tail, N, K, stream,
-                     aux ? (bf16*)aux + main * ldaux : nullptr, ldaux);
+    launch256<EPI, F8>(A, lda, W, bias, C, ldc, main, N, K, stream, aux, ldaux, ws, xs);
+    const float* xt = xs ? xs + main : nullptr;
+    if (!launch_tail_splitk<EPI, F8>((const bf16*)A + main * lda, lda, W, bias, (char*)C + main * ldc * esz, ldc, tail, N, K, stream, ws, xt))
+      launch128<EPI, F8>((const bf16*)A + main * lda, lda, W, bias, (char*)C + main * ldc * esz, ldc, tail, N, K, stream,
+                         aux ? (bf16*)aux + main * ldaux : nullptr, ldaux, ws, xt);
   } else {
-    launch128<EPI>(A, lda, W, bias, C, ldc, M, N, K, stream, aux, ldaux);
+    launch128<EPI, F8>(A, lda, W, bias, C, ldc, M, N, K, stream, aux, ldaux, ws, xs);
   }
-  return vr2_check_launch("vr2_gemm_bf16");
+  return vr2_check_launch(F8 ? "vr2_gemm_a8w8" : "vr2_gemm_bf16");
 }
 
 }  // namespace
@@ -458,4 +534,29 @@ extern "C" int vr2_gemm_swiglu_save(const void* A, int64_t lda, const void* Wpac
   VR2_REQUIRE(lda % 8 == 0 && lda >= K && ldact % 4 == 0 && ldact >= N / 2 && ldgu % 4 == 0 && ldgu >= N && gu_bf16 != nullptr,
               "vr2_gemm_swiglu_save: bad strides");
   return launch<EPI_SWIGLU_BF16>(A, lda, Wpacked, bias_f32, act_bf16, ldact, M, N, K, stream, gu_bf16, ldgu);
+}
+
+// BASELINE config 5, the no-grad GEMMs on the fp8 matrix path: C (op)= (q_x q_w^T) * scale_x[m] * scale_w[n] + bias.  x = the
+// e4m3 bytes + per-row scales of vr2_quant_rows_fp8 / vr2_add_rmsnorm_q8, W = the per-channel e4m3 tiles of vr2_gemv_w8 (one
+// fp8 copy of a weight serves the decode GEMVs and these GEMMs).  Same tilings, staging and epilogues as vr2_gemm_bf16; the
+// multiply is v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (twice the bf16 MFMA rate on half the staged bytes).
+extern "C" int vr2_gemm_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, const void* Wpacked_fp8, const void* wscale_f32,
+                             const void* bias_f32, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, void* stream) {
+  VR2_REQUIRE(M >= 1 && N >= 4 && K >= 128 && K % 128 == 0, "vr2_gemm_a8w8: bad shape M=%ld N=%ld K=%ld (K %% 128)", (long)M, (long)N, (long)K);
+  VR2_REQUIRE(N % 4 == 0 && ldx8 % 16 == 0 && ldx8 >= K && ldc % 4 == 0, "vr2_gemm_a8w8: N %% 4, ldx8 %% 16, ldc %% 4");
+  VR2_REQUIRE(ldc >= N || epilogue == EPI_SWIGLU_BF16, "vr2_gemm_a8w8: ldc smaller than the row length");
+  VR2_REQUIRE(xscale_f32 && wscale_f32, "vr2_gemm_a8w8: scales missing");
+  const float* ws = (const float*)wscale_f32;
+  const float* xs = (const float*)xscale_f32;
+  const int64_t lda = ldx8 / 2, K2 = K / 2;     // the kernels address the bytes in pairs
+  switch (epilogue) {
+    case EPI_BF16: return launch<EPI_BF16, true>(x_fp8, lda, Wpacked_fp8, bias_f32, C, ldc, M, N, K2, stream, nullptr, 0, ws, xs);
+    case EPI_F32: return launch<EPI_F32, true>(x_fp8, lda, Wpacked_fp8, bias_f32, C, ldc, M, N, K2, stream, nullptr, 0, ws, xs);
+    case EPI_ADD_F32: return launch<EPI_ADD_F32, true>(x_fp8, lda, Wpacked_fp8, bias_f32, C, ldc, M, N, K2, stream, nullptr, 0, ws, xs);
+    case EPI_SWIGLU_BF16:
+      VR2_REQUIRE(N % 32 == 0 && ldc >= N / 2, "vr2_gemm_a8w8: SwiGLU epilogue needs N %% 32 == 0 (interleaved gate/up tiles)");
+      return launch<EPI_SWIGLU_BF16, true>(x_fp8, lda, Wpacked_fp8, bias_f32, C, ldc, M, N, K2, stream, nullptr, 0, ws, xs);
+  }
+  vr2_set_error("vr2_gemm_a8w8: epilogue %d not built for fp8 operands", epilogue);
+  return -1;
 }

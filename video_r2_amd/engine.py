@@ -91,6 +91,9 @@ class Engine:
         self.decode_fp8 = False      # decode GEMVs stream per-channel e4m3 weight copies (weights.add_fp8_decode_copies; config 5)
         self.decode_fp8_max_rows = 128
         self.decode_fp8_act = True   # ... and, above 16 rows, fp8 ACTIVATIONS on the fp8 MFMA (vr2_quant_rows_fp8 + vr2_gemv_a8w8)
+        self.gemm_fp8 = False        # config 5, the no-grad LM passes (prompt prefill, teacher-forced scoring): per-row e4m3
+                                     # activations x the same per-channel e4m3 weight copies on the block-scaled fp8 MFMA
+                                     # (vr2_gemm_a8w8); the training forward / backward stay bf16
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -123,6 +126,30 @@ class Engine:
     def _gemm(self, A, P: Params, wname, bias, C, M, epi):
         n, kp = P.shape[wname]
         lib.call("vr2_gemm_bf16", A, A.stride(0), P[wname], bias, C, C.stride(0), M, n, kp, epi, self.s)
+
+    def _lm_f8(self, P: Params):
+        """the fp8 GEMM path of _lm_rows / _logits_rows applies: mode on, P carries fp8 copies, every K a multiple of 128"""
+        if not self.gemm_fp8:
+            return False
+        f8 = getattr(P, "f8", None)
+        if not f8:
+            raise lib.Vr2Error("gemm_fp8 is on but the parameters have no fp8 copies: call weights.add_fp8_decode_copies(params) first")
+        t = self.cfg.text
+        return all(k % 128 == 0 for k in (t.hidden_size, t.intermediate_size, t.num_attention_heads * t.head_dim)) and t.hidden_size <= 4096
+
+    def _gemm8(self, q8, xs, P: Params, wname, bias, C, M, epi):
+        n, kp = P.shape[wname]
+        w8, ws = P.f8[wname]
+        lib.call("vr2_gemm_a8w8", q8, q8.stride(0), xs, w8, ws, bias, C, C.stride(0), M, n, kp, epi, self.s)
+
+    def _quant_rows(self, x, M, K, tag):
+        """bf16 rows -> (e4m3 bytes, per-row scales) in a workspace of the calling pass (not the decode graph's)"""
+        t = self.cfg.text
+        width = 128 * ((max(t.intermediate_size, t.hidden_size, t.num_attention_heads * t.head_dim) + 127) // 128)
+        q8, xs = self.buf(tag + ".q8", (M, width), torch.uint8), self.buf(tag + ".q8s", (M,), torch.float32)
+        if x is not None:
+            lib.call("vr2_quant_rows_fp8", x, x.stride(0), M, K, q8, q8.stride(0), xs, self.s)
+        return q8, xs
 
     def _f8(self, P: Params, wname, rows=1):
         """(packed fp8 weights, scales) when fp8 decode weights are enabled and P carries them (weights.add_fp8_decode_copies).
@@ -387,13 +414,18 @@ class Engine:
         att = self.buf(tag + ".att", (T, nq * hd), torch.bfloat16)
         act = self.buf(tag + ".act", (T, I), torch.bfloat16)
         scale = hd ** -0.5
+        f8 = self._lm_f8(W)
+        qx = self._quant_rows(None, T, 0, tag) if f8 else None       # (bytes, scales) workspace of this pass
         for l in range(t.num_hidden_layers):
             ko = k_own[l] if k_own.dim() == 3 else k_own
             vo = v_own[l] if v_own.dim() == 3 else v_own
             ka = ko if kA is None else kA[l]
             va = vo if vA is None else vA[l]
-            self._norm(x, W[f"l{l}.ln1"], xn, T, H, t.rms_norm_eps)
-            self._gemm(xn, W, f"l{l}.qkv_w", W[f"l{l}.qkv_b"], qkv, T, EPI_F32)
+            self._norm(x, W[f"l{l}.ln1"], xn, T, H, t.rms_norm_eps, q8=qx)
+            if f8:
+                self._gemm8(*qx, W, f"l{l}.qkv_w", W[f"l{l}.qkv_b"], qkv, T, EPI_F32)
+            else:
+                self._gemm(xn, W, f"l{l}.qkv_w", W[f"l{l}.qkv_b"], qkv, T, EPI_F32)
             if seg is None:
                 lib.call("vr2_rope_qkv", qkv, qkv.stride(0), cos, sin, T, nq, nkv, hd, qb, qb.stride(0), ko, vo, ko.stride(0), own_row0, self.s)
             else:
@@ -401,6 +433,12 @@ class Engine:
                          seg[0], seg[1], self.s)
             lib.call("vr2_attn_tok", work, work.shape[0], qb, qb.stride(0), ka, va, ko, vo, ko.stride(0), att,
                      att.stride(0), nq, t.group, hd, scale, None, self.s)
+            if f8:
+                self._gemm8(*self._quant_rows(att, T, nq * hd, tag), W, f"l{l}.o_w", None, x, T, EPI_ADD_F32)
+                self._norm(x, W[f"l{l}.ln2"], xn, T, H, t.rms_norm_eps, q8=qx)
+                self._gemm8(*qx, W, f"l{l}.gu_w", None, act, T, EPI_SWIGLU_BF16)
+                self._gemm8(*self._quant_rows(act, T, I, tag), W, f"l{l}.down_w", None, x, T, EPI_ADD_F32)
+                continue
             self._gemm(att, W, f"l{l}.o_w", None, x, T, EPI_ADD_F32)
             self._norm(x, W[f"l{l}.ln2"], xn, T, H, t.rms_norm_eps)
             self._gemm(xn, W, f"l{l}.gu_w", None, act, T, EPI_SWIGLU_BF16)
@@ -410,6 +448,11 @@ class Engine:
     def _logits_rows(self, W: Params, x, T, out):
         t = self.cfg.text
         xn = self.buf("lm.hn%d" % T, (T, t.hidden_size), torch.bfloat16)
+        if T > 16 and self._lm_f8(W) and "lm_head" in W.f8:
+            qx = self._quant_rows(None, T, 0, "lm")
+            self._norm(x, W["norm"], xn, T, t.hidden_size, t.rms_norm_eps, q8=qx)
+            self._gemm8(*qx, W, "lm_head", None, out, T, EPI_F32)
+            return out
         self._norm(x, W["norm"], xn, T, t.hidden_size, t.rms_norm_eps)
         self._gemm(xn, W, "lm_head", None, out, T, EPI_F32)
         return out

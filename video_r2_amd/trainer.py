@@ -131,6 +131,10 @@ class QwenGRPOTrainer:
             vw.add_fp8_decode_copies(model.text)
             model.engine.decode_fp8 = True
             model.engine.decode_fp8_act = args.decode_weights == "fp8"     # fp8w: weight-only (bf16 activations)
+            if args.decode_weights == "fp8":     # ... and the no-grad LM GEMMs (rollout prefill, reference prefill + log-probs) on
+                if self.ref_params is not None:  # fp8 operands too (vr2_gemm_a8w8); the reference model is frozen: quantised once
+                    vw.add_fp8_decode_copies(self.ref_params)
+                model.engine.gemm_fp8 = True
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
         self._row_pool = None                        # --reward_workers threads that split a reward function's rows
         self.update = not getattr(args, "freeze_llm", False)

@@ -116,3 +116,20 @@ def test_7b_cross_path_properties(frames, G):
     for m_, x_ in errs.values():
         assert m_ < 8e-2 and x_ < 0.3            # measured 3.3e-2 / 7.6e-2 (weights) and 5.1e-2 / 1.8e-1 (+ activations) on random weights
     assert errs["fp8 weights + activations (fp8 MFMA)"][0] < 4 * errs["fp8 weights"][0] + 1e-2
+    # 6. config 5, the no-grad GEMMs (Engine.gemm_fp8): prompt prefill + teacher-forced scoring of the same tokens with every LM
+    #    projection and the lm_head on per-row e4m3 activations x per-channel e4m3 weights (block-scaled fp8 MFMA) against the bf16
+    #    scoring pass -- all G x C log-probs.  Bars as in 5: a small perturbation of the bf16 model, same order as the decode's.
+    eng.gemm_fp8 = True
+    try:
+        st8 = eng.prefill(pol, ids, emb, plan, [1.0])
+        lp8 = eng.score(pol, st8, toks, T).float().clone()
+        eng.sync()
+    finally:
+        eng.gemm_fp8 = False
+    st = eng.prefill(pol, ids, emb, plan, [1.0])
+    lpb = eng.score(pol, st, toks, T).float()
+    eng.sync()
+    r6 = rel(lp8, lpb)
+    print("7B config 5, prefill + scoring on fp8 operands: logp rel err vs the bf16 pass mean %.2e p95 %.2e max %.2e; mean |dlogp| %.3e"
+          % (r6.mean().item(), r6.flatten().quantile(0.95).item(), r6.max().item(), (lp8 - lpb).abs().mean().item()))
+    assert r6.mean().item() < 8e-2 and r6.flatten().quantile(0.95).item() < 0.3

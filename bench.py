@@ -278,7 +278,10 @@ def main():
         toks_all, _ = eng.decode(pol, states, G, C, temperature=0.9, top_k=50, seed=1000 * rank + i, eos_token_id=None,
                                  use_graph=not a.no_graph)
         mark("decode")
-        loss = 0.0
+        eng.sync()
+        comp_all = toks_all.cpu().numpy()                              # the rewards are host functions of the completions: ONE copy
+        rew_all = torch.from_numpy(stub_rewards(comp_all)).to(device)  # per step, no host sync inside the loop over the groups
+        losses = []
         mark(None)
         ref_states = eng.prefill_batch(ref, [(ids, enc[p_][0], enc[p_][1], [1.0]) for p_, (_, _, ids) in enumerate(mine)], ref_slots[:Pn], tag="ref")
         mark("ref_prefill+ref_score")
@@ -290,18 +293,15 @@ def main():
             mark("ref_prefill+ref_score")
             lp = eng.score(pol, states[p_], toks, 0.9, tag="pol") if upd is None else upd.forward(ids, emb, plan, [1.0], toks, 0.9)
             mark("policy_forward")
-            eng.sync()
-            comp = toks.cpu().numpy()
-            mark(None)
             with torch.cuda.stream(eng.stream):
                 mask, _, _ = hg.completion_mask(toks, -1)
-                adv = hg.group_advantages(torch.from_numpy(stub_rewards(comp)).to(device), [1.0], G, loss_type="bnpo")["advantages"]
+                adv = hg.group_advantages(rew_all[p_ * G:(p_ + 1) * G], [1.0], G, loss_type="bnpo")["advantages"]
                 out = hg.grpo_loss(lp, mask, adv, ref_logps=lp_ref, beta=0.04, loss_type="bnpo", stream=eng.s)
             if upd is not None:
                 upd.backward(out["dlogp"], exchange=(p_ == Pn - 1))    # gradients accumulate over the groups; the last backward
                                                                        # puts each layer's bucket on the wire as it completes
             mark("loss+backward")
-            loss += float(out["loss"].item()) / Pn
+            losses.append(out["loss"])
         mark(None)
         if upd is not None:
             upd.optimizer_step(lr=1e-6, weight_decay=0.01, max_grad_norm=1.0, grad_scale=1.0 / Pn)   # + RCCL all-reduce for N>1
@@ -310,7 +310,7 @@ def main():
                     W.add_fp8_decode_copies(pol)                     # the next rollout decodes the updated policy
         mark("clip+adamw(+allreduce)")
         eng.sync()
-        return loss
+        return float(sum(float(l.item()) for l in losses)) / Pn
 
     def barrier():
         torch.cuda.synchronize()
@@ -543,10 +543,11 @@ def main():
             line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.model, a.frames, G, C)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.barrier()                 # rank 0 times its roofline kernels after the last collective: the others wait here, so the
+        dist.destroy_process_group()   # communicator is torn down by all ranks together
 
 
 if __name__ == "__main__":

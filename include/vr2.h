@@ -165,6 +165,17 @@ int vr2_attn_decode(const void* Q_bf16, int64_t ldq, const void* Kprefix, const 
 int vr2_sample_topk(const void* logits_f32, int64_t ldl, int64_t G, int64_t V, float temperature, int top_k,
                     uint64_t seed, const void* seed_dev_u64, const void* step_i32, void* finished_i32, int eos_id,
                     int pad_id, void* next_ids_i32, void* tokens_i32, int64_t ldt, void* cand_ws, void* stream);
+/* the same with HF's nucleus (top_p) and min-p warpers applied after top-k, in HF's order (TopPLogitsWarper, MinPLogitsWarper of
+ * generation/logits_process.py; the reference forwards both flags to generate, grpo_trainer.py:559-570).  top_p = 1 and min_p = 0
+ * are vr2_sample_topk; otherwise 1 <= top_k <= 64 and the candidate workspace are required (the warpers run on the top-k set). */
+int vr2_sample_topk_p(const void* logits_f32, int64_t ldl, int64_t G, int64_t V, float temperature, int top_k, float top_p,
+                      float min_p, uint64_t seed, const void* seed_dev_u64, const void* step_i32, void* finished_i32, int eos_id,
+                      int pad_id, void* next_ids_i32, void* tokens_i32, int64_t ldt, void* cand_ws, void* stream);
+/* HF RepetitionPenaltyLogitsProcessor on the raw logits, before the warpers: ids seen so far (prompt + generated) get
+ * logit < 0 ? logit * penalty : logit / penalty.  seen_bits: [G][words_per_row] uint32 bitmap kept by the caller across steps
+ * (prompt ids set beforehand); new_ids (nullable): the token each row appended since the last call, set here. */
+int vr2_repetition_penalty(void* logits_f32, int64_t ldl, int64_t G, int64_t V, float penalty, void* seen_bits_u32,
+                           int64_t words_per_row, const void* new_ids_i32, void* stream);
 /* bytes of the optional two-stage workspace `cand_ws` (NULL = single-pass kernel) */
 int64_t vr2_sample_ws_bytes(int64_t G);
 /* logp[r] = logits[r][tok[r]]/T - logsumexp(logits[r]/T)  (trl.selective_log_softmax via grpo_trainer.py:738-739, K15) */

@@ -356,14 +356,37 @@ def per_token_logps(w, cfg, input_ids, attention_mask, logits_to_keep, temperatu
     return selective_log_softmax(logits, tgt)
 
 
-def warp_logits(logits, temperature, top_k):
-    """HF:generation/logits_process.py:238 (temperature) and :542 (top-k: keep scores >= k-th largest)."""
+def warp_logits(logits, temperature, top_k, top_p=1.0, min_p=None):
+    """HF:generation/logits_process.py: temperature (:238), top-k (:542: keep scores >= k-th largest), then -- in HF's warper order --
+    TopPLogitsWarper (ascending sort, drop tokens whose cumulative probability is <= 1 - top_p, keep at least one) and
+    MinPLogitsWarper (drop tokens with probability < min_p * max probability, keep at least one)."""
     s = logits / temperature
     if top_k and top_k > 0:
         k = min(top_k, s.shape[-1])
         kth = torch.topk(s, k)[0][..., -1, None]
         s = s.masked_fill(s < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        srt, idx = torch.sort(s, descending=False, dim=-1)
+        cum = srt.softmax(-1).cumsum(-1)
+        rm = cum <= (1 - top_p)
+        rm[..., -1:] = False
+        s = s.masked_fill(rm.scatter(-1, idx, rm), float("-inf"))
+    if min_p is not None and min_p > 0.0:
+        pr = s.softmax(-1)
+        rm = pr < min_p * pr.max(-1, keepdim=True)[0]
+        top = s.argmax(-1, keepdim=True)
+        rm.scatter_(-1, top, False)
+        s = s.masked_fill(rm, float("-inf"))
     return s
+
+
+def repetition_penalty(logits, seen_ids, penalty):
+    """HF RepetitionPenaltyLogitsProcessor: for the ids of the sequence so far (row-wise), score < 0 ? score * penalty : score / penalty;
+    an id that occurs several times is penalised once (gather -> modify -> scatter)."""
+    ids = torch.as_tensor(seen_ids, dtype=torch.long)
+    sc = torch.gather(logits, -1, ids)
+    sc = torch.where(sc < 0, sc * penalty, sc / penalty)
+    return logits.scatter(-1, ids, sc)
 
 
 def generate(w, cfg: Cfg, input_ids, attention_mask, pixel_values_videos, video_grid_thw, second_per_grid_ts,

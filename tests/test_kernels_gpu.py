@@ -716,3 +716,71 @@ def test_gemm_fp8_operands_on_the_scaled_mfma(dev, M, N, K):
     xq = (_deinterleave_fp8_rows(q8[:, :K].cpu(), K).view(torch.float8_e4m3fn).float() * xs.cpu()[:, None]).double()
     wi = xq @ dequantize_rows_fp8(qwi, swi).double().t()
     assert (out.cpu().double() - wi).abs().max() <= 2e-6 * wi.abs().max()
+
+
+@pytest.mark.parametrize("T,k,top_p,min_p", [(0.9, 50, 0.9, 0.0), (0.7, 50, 0.5, 0.05), (1.3, 20, 1.0, 0.2), (0.9, 64, 0.99, 0.01)])
+def test_sample_top_p_and_min_p_match_the_hf_warpers(dev, T, k, top_p, min_p):
+    """vr2_sample_topk_p: the support of the draws is EXACTLY the set HF's temperature -> top-k -> top-p -> min-p warpers keep
+    (oracle.model.warp_logits, itself pinned against the HF classes on CPU) and the frequencies follow the renormalised
+    distribution (chi-square); top_p = 1, min_p = 0 reproduces vr2_sample_topk draw for draw; requests the two-stage path cannot
+    serve are refused."""
+    from oracle import model as om
+    V, G = 4096, 8
+    ws = torch.zeros(int(lib.load().vr2_sample_ws_bytes(G)) // 4, device=dev)
+    g = torch.Generator().manual_seed(5)
+    logits = (3.0 * torch.randn(1, V, generator=g))
+    kept = om.warp_logits(logits, T, k, top_p, min_p or None)[0]
+    keep = ~torch.isinf(kept)
+    p = kept.softmax(-1)
+    ld = logits.to(dev)
+    nxt = torch.zeros(G, dtype=torch.int32, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    counts = torch.zeros(V)
+    for it in range(600):
+        lib.call("vr2_sample_topk_p", ld, 0, G, V, T, k, top_p, min_p, 4321 + it, None, step, None, -1, 0, nxt, None, 0, ws, S())
+        counts += torch.bincount(nxt.cpu().long(), minlength=V).float()
+    assert counts[~keep].sum().item() == 0, "a token outside the warped set was drawn"
+    n = counts.sum().item()
+    exp = p * n
+    assert bool((counts[exp > 20] > 0).all()), "a kept token with sizeable probability never appeared"
+    sel = exp > 5
+    if int(sel.sum()) > 1:
+        chi2 = (((counts - exp) ** 2)[sel] / exp[sel]).sum().item()
+        dof = int(sel.sum().item()) - 1
+        assert chi2 < dof + 6 * (2 * dof) ** 0.5, (chi2, dof)
+    a = torch.zeros(G, dtype=torch.int32, device=dev); b = torch.zeros(G, dtype=torch.int32, device=dev)
+    lib.call("vr2_sample_topk_p", ld, 0, G, V, T, k, 1.0, 0.0, 77, None, step, None, -1, 0, a, None, 0, ws, S())
+    lib.call("vr2_sample_topk", ld, 0, G, V, T, k, 77, None, step, None, -1, 0, b, None, 0, ws, S())
+    assert torch.equal(a, b)
+    L = lib.load()
+    assert L.vr2_sample_topk_p(ld.data_ptr(), 0, G, V, T, 200, 0.9, 0.0, 1, None, step.data_ptr(), None, -1, 0, nxt.data_ptr(), None, 0, ws.data_ptr(), None) != 0
+    assert b"top_k" in L.vr2_last_error()
+
+
+def test_repetition_penalty_matches_hf_and_tracks_new_tokens(dev):
+    """vr2_repetition_penalty against oracle.model.repetition_penalty (pinned against HF's RepetitionPenaltyLogitsProcessor): ids
+    seen so far are penalised ONCE whatever their multiplicity, the token appended since the last call is folded into the bitmap"""
+    from oracle import model as om
+    G, V = 5, 3001
+    g = torch.Generator().manual_seed(8)
+    x = 2.0 * torch.randn(G, V, generator=g)
+    prompt = torch.randint(0, V, (G, 30), generator=g)
+    prompt[:, 5] = prompt[:, 4]                                   # a repeated id
+    words = (V + 31) // 32
+    bits = np.zeros((G, words * 32), dtype=bool)
+    for r in range(G):
+        bits[r, prompt[r].numpy()] = True
+    seen = torch.from_numpy(np.packbits(bits, axis=1, bitorder="little").view(np.int32).copy()).to(dev)
+    xd = x.clone().to(dev)
+    lib.call("vr2_repetition_penalty", xd, V, G, V, 1.3, seen, words, None, S())
+    assert torch.equal(xd.cpu(), om.repetition_penalty(x, prompt, 1.3))
+    new = torch.tensor([7, 3000, int(prompt[2, 0]), 64, 31], dtype=torch.int32)
+    x2 = 2.0 * torch.randn(G, V, generator=g)
+    xd2 = x2.clone().to(dev)
+    lib.call("vr2_repetition_penalty", xd2, V, G, V, 0.8, seen, words, new.to(dev), S())
+    hist = torch.cat([prompt, new.long()[:, None]], 1)
+    assert torch.equal(xd2.cpu(), om.repetition_penalty(x2, hist, 0.8))
+    x3 = 2.0 * torch.randn(G, V, generator=g)
+    xd3 = x3.clone().to(dev)
+    lib.call("vr2_repetition_penalty", xd3, V, G, V, 1.1, seen, words, None, S())      # the new ids stayed in the bitmap
+    assert torch.equal(xd3.cpu(), om.repetition_penalty(x3, hist, 1.1))

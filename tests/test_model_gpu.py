@@ -106,9 +106,13 @@ def test_rows_with_equal_ids_but_different_videos_are_not_merged():
     out = m.generate(input_ids=ids, attention_mask=am, pixel_values_videos=pvt, video_grid_thw=gtt, second_per_grid_ts=[1.0] * 4,
                      generation_config=GenerationConfig(max_new_tokens=4, eos_token_id=-1, seed=3))
     assert out.shape == (4, ids.shape[1] + 4)
-    with pytest.raises(ValueError, match="top-k only"):
-        m.generate(input_ids=ids, attention_mask=am, pixel_values_videos=pvt, video_grid_thw=gtt,
-                   generation_config=GenerationConfig(max_new_tokens=4, top_p=0.9))
+    # nucleus / min-p / repetition penalty ride on the top-k candidate path (HF's warper order); outside it they are refused
+    out_p = m.generate(input_ids=ids, attention_mask=am, pixel_values_videos=pvt, video_grid_thw=gtt, second_per_grid_ts=[1.0] * 4,
+                       generation_config=GenerationConfig(max_new_tokens=4, eos_token_id=-1, seed=3, top_p=0.9, min_p=0.02, repetition_penalty=1.2))
+    assert out_p.shape == (4, ids.shape[1] + 4)
+    with pytest.raises(ValueError, match="top_k"):
+        m.generate(input_ids=ids, attention_mask=am, pixel_values_videos=pvt, video_grid_thw=gtt, second_per_grid_ts=[1.0] * 4,
+                   generation_config=GenerationConfig(max_new_tokens=4, top_p=0.9, top_k=200))
 
 
 def test_generate_with_hf_keyword_arguments_as_the_eval_harness_calls_it():
@@ -140,8 +144,20 @@ def test_generate_with_hf_keyword_arguments_as_the_eval_harness_calls_it():
         assert tok == int(top2.indices[j, 0]) or float(top2.values[j, 0] - top2.values[j, 1]) < 2e-2, j
     with pytest.raises(ValueError, match="beam"):
         m.generate(**kw, num_beams=4, max_new_tokens=2)
-    with pytest.raises(ValueError, match="top-k only"):
-        m.generate(**kw, do_sample=True, temperature=0.7, top_p=0.9, max_new_tokens=2)
+    # sampling with HF's warpers: every drawn token lies in the set the oracle's warpers keep for ITS step (teacher-forced oracle on
+    # the engine's own tokens); a repetition penalty > 1 is applied to prompt + generated ids before them
+    outs = m.generate(**kw, eos_token_id=-1, pad_token_id=cfg.pad_token_id, do_sample=True, temperature=0.7, top_k=20, top_p=0.8, min_p=0.05,
+                      repetition_penalty=1.3, max_new_tokens=C)
+    fulls = outs.cpu()
+    lg = om.forward_logits(w, ocfg, fulls, np.ones_like(fulls.numpy()), torch.from_numpy(px), np.asarray([grid]), [1.0])
+    for j in range(C):
+        raw = om.repetition_penalty(lg[0, S - 1 + j][None], fulls[:, :S + j], 1.3)
+        kept = om.warp_logits(raw, 0.7, 20, 0.8, 0.05)[0]
+        tok = int(fulls[0, S + j])
+        near = (kept.exp().sum() > 0) and bool(torch.isfinite(kept[tok]))
+        if not near:   # bf16-level logit noise can move a token across a warper's boundary: accept it within 2e-2 of the kept set's edge
+            edge = kept[torch.isfinite(kept)].min()
+            assert float(edge - raw[0, tok] / 0.7) < 5e-2, (j, tok)
     with pytest.raises(NotImplementedError):
         m.generate(**kw, pixel_values=torch.zeros(4, 1176), max_new_tokens=2)
 

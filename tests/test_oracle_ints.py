@@ -194,3 +194,28 @@ def test_resize_restatement_is_torch_bit_for_bit(h, w, oh, ow):
         assert bits == prec and first.tolist() == [t[0] for t in taps] and count.tolist() == [len(t[1]) for t in taps]
         for i, (_, ws) in enumerate(taps):
             assert wt[i, :len(ws)].tolist() == ws and not wt[i, len(ws):].any()
+
+
+def test_oracle_warpers_match_hf_logits_processors():
+    """oracle.model.warp_logits / repetition_penalty (the checkers of the device sampler's top_p / min_p / repetition penalty) against
+    the HF classes the reference's generate call reaches (transformers' TopK / TopP / MinP warpers, RepetitionPenaltyLogitsProcessor)."""
+    import pytest
+    import torch
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    from oracle import model as om
+    g = torch.Generator().manual_seed(11)
+    x = 3.0 * torch.randn(5, 997, generator=g)
+    ids = torch.randint(0, 997, (5, 40), generator=g)
+    for T, k, tp, mp in [(0.9, 50, 0.9, None), (0.7, 50, 0.5, 0.05), (1.3, 20, 1.0, 0.2), (0.9, 64, 0.99, 0.01), (1.0, 7, 0.3, None)]:
+        want = lp.TopKLogitsWarper(top_k=k)(ids, lp.TemperatureLogitsWarper(T)(ids, x.clone()))
+        if tp < 1.0:
+            want = lp.TopPLogitsWarper(top_p=tp)(ids, want)
+        if mp:
+            want = lp.MinPLogitsWarper(min_p=mp)(ids, want)
+        got = om.warp_logits(x, T, k, tp, mp)
+        assert torch.equal(torch.isinf(got), torch.isinf(want)), (T, k, tp, mp)
+        keep = ~torch.isinf(want)
+        assert torch.allclose(got[keep], want[keep])
+    for pen in (1.3, 0.8):
+        want = lp.RepetitionPenaltyLogitsProcessor(penalty=pen)(ids, x.clone())
+        assert torch.equal(om.repetition_penalty(x, ids, pen), want)

@@ -190,8 +190,14 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(const float* __res
   }
 }
 
+// top_p < 1 / min_p > 0: the nucleus and min-p warpers of HF generate, applied in its order AFTER top-k on the temperature-scaled
+// scores (generation/logits_process.py TopPLogitsWarper / MinPLogitsWarper; the reference forwards both flags to generate,
+// grpo_trainer.py:559-570).  With p = softmax over the top-k set: a token stays iff the mass of the STRICTLY better tokens is
+// below top_p (HF removes ascending-sorted tokens whose cumulative mass is <= 1 - top_p: the same set; tokens tied in score are
+// kept or dropped together here) and iff p >= min_p * p_max (the best token survives top-p, so the renormalisation cancels).
 __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                                                                float inv_temp, int top_k, unsigned long long seed_arg,
+                                                                float inv_temp, int top_k, float top_p, float min_p,
+                                                                unsigned long long seed_arg,
                                                                 const unsigned long long* __restrict__ seed_dev,
                                                                 const int* __restrict__ step, int* __restrict__ finished,
                                                                 int eos_id, int pad_id, int* __restrict__ next_ids,
@@ -226,11 +232,46 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* __r
   const unsigned k = (unsigned)top_k < total ? (unsigned)top_k : total;
   const unsigned thr = radix_select_256<NK>(key, k, hist, bc);
   const unsigned st = (unsigned)step[0];
+  unsigned drop = 0u;                       // bit j: candidate j of this thread was removed by a warper (a mask, not key[j] = 0: hipcc
+                                            // 7.2 lost that store for j = 0 when only min_p applied -- seen in the ISA and in the draws)
+  if (top_p < 1.0f || min_p > 0.0f) {       // wave-uniform: kernel arguments
+    constexpr int LCAP = 512;                // kept scores (top-k + ties): beyond this many the warpers see the first LCAP only
+    __shared__ float ls[LCAP];
+    __shared__ int ln;
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+      if (key[j] != 0u && key[j] >= thr) m = fmaxf(m, val[j] * inv_temp);
+    m = block_max_256(m, red_v);
+    if (tid == 0) ln = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+      if (key[j] != 0u && key[j] >= thr) {
+        const int slot = atomicAdd(&ln, 1);
+        if (slot < LCAP) ls[slot] = val[j] * inv_temp;
+      }
+    __syncthreads();
+    const int n = ln < LCAP ? ln : LCAP;
+    float Z = 0.f;
+    for (int i = 0; i < n; ++i) Z += __expf(ls[i] - m);        // every thread the same order: identical Z
+    const float lim = top_p * Z;
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+      if (key[j] != 0u && key[j] >= thr) {
+        const float sj = val[j] * inv_temp;
+        float better = 0.f;
+        for (int i = 0; i < n; ++i) better += ls[i] > sj ? __expf(ls[i] - m) : 0.f;
+        const bool keep = (top_p >= 1.0f || better < lim) && (__expf(sj - m) >= min_p);
+        if (!keep) drop |= 1u << j;                           // dropped by a warper: out of the draw
+      }
+    __syncthreads();
+  }
   float best = -INFINITY;
   int besti = 0x7fffffff;
 #pragma unroll
   for (int j = 0; j < NK; ++j) {
-    if (key[j] != 0u && key[j] >= thr) {
+    if (key[j] != 0u && key[j] >= thr && !((drop >> j) & 1u)) {
       const float u = philox_uniform(seed, (unsigned)idx[j], (unsigned)g, st);
       const float sc = val[j] * inv_temp - __logf(-__logf(u));
       if (sc > best || (sc == best && idx[j] < besti)) { best = sc; besti = idx[j]; }
@@ -397,11 +438,52 @@ __global__ __launch_bounds__(256) void grpo_loss_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int vr2_sample_topk(const void* logits_f32, int64_t ldl, int64_t G, int64_t V, float temperature, int top_k,
-                               uint64_t seed, const void* seed_dev_u64, const void* step_i32, void* finished_i32,
-                               int eos_id, int pad_id, void* next_ids_i32, void* tokens_i32, int64_t ldt, void* cand_ws,
-                               void* stream) {
+// HF RepetitionPenaltyLogitsProcessor (generation/logits_process.py; grpo_trainer.py:559-570 forwards the flag): for every token id
+// that occurs in the sequence so far (prompt + generated), logit = logit < 0 ? logit * penalty : logit / penalty -- once per id.
+// seen: one bit per vocabulary entry and row, kept across the decode steps; new_ids[g] (the token appended since the last call) is
+// folded in here by the thread that owns its word.
+__global__ __launch_bounds__(256) void repetition_penalty_kernel(float* __restrict__ logits, long ldl, int V, float penalty,
+                                                                 unsigned* __restrict__ seen, int words, const int* __restrict__ new_ids) {
+  const int g = blockIdx.y;
+  unsigned* sb = seen + (long)g * words;
+  int tw = -1;
+  unsigned tb = 0u;
+  if (new_ids) {
+    const int t = new_ids[g];
+    if (t >= 0 && t < V) { tw = t >> 5; tb = 1u << (t & 31); }
+  }
+  float* row = logits + (long)g * ldl;
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) {
+    unsigned bits = sb[w];
+    if (w == tw) { bits |= tb; sb[w] = bits; }     // (the grid-stride loop hands every word to exactly one thread)
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      const int i = w * 32 + b;
+      if (i < V) { const float l = row[i]; row[i] = l < 0.f ? l * penalty : l / penalty; }
+    }
+  }
+}
+
+extern "C" int vr2_repetition_penalty(void* logits_f32, int64_t ldl, int64_t G, int64_t V, float penalty, void* seen_bits_u32,
+                                      int64_t words_per_row, const void* new_ids_i32, void* stream) {
+  VR2_REQUIRE(G >= 1 && V >= 1 && penalty > 0.f && words_per_row * 32 >= V, "vr2_repetition_penalty: bad arguments (penalty > 0, words * 32 >= V)");
+  const unsigned bx = (unsigned)((words_per_row + 255) / 256);
+  hipLaunchKernelGGL(repetition_penalty_kernel, dim3(bx, (unsigned)G), dim3(256), 0, (hipStream_t)stream, (float*)logits_f32, (long)ldl,
+                     (int)V, penalty, (unsigned*)seen_bits_u32, (int)words_per_row, (const int*)new_ids_i32);
+  return vr2_check_launch("vr2_repetition_penalty");
+}
+
+extern "C" int vr2_sample_topk_p(const void* logits_f32, int64_t ldl, int64_t G, int64_t V, float temperature, int top_k,
+                                 float top_p, float min_p, uint64_t seed, const void* seed_dev_u64, const void* step_i32,
+                                 void* finished_i32, int eos_id, int pad_id, void* next_ids_i32, void* tokens_i32, int64_t ldt,
+                                 void* cand_ws, void* stream) {
   VR2_REQUIRE(G >= 1 && V >= 1 && temperature > 0.f, "vr2_sample_topk: bad arguments (temperature must be > 0)");
+  VR2_REQUIRE(top_p > 0.f && top_p <= 1.f && min_p >= 0.f && min_p <= 1.f, "vr2_sample_topk_p: top_p=%g must be in (0,1], min_p=%g in [0,1]", top_p, min_p);
+  const bool warp = top_p < 1.f || min_p > 0.f;
+  VR2_REQUIRE(!warp || (cand_ws != nullptr && top_k >= 1 && top_k <= CAND && V <= NSLICE * 256 * NJ),
+              "vr2_sample_topk_p: top_p / min_p are built on the two-stage top-k path: they need 1 <= top_k <= %d (got %d) and the "
+              "candidate workspace", CAND, top_k);
   if (cand_ws != nullptr && top_k >= 1 && top_k <= CAND && V <= NSLICE * 256 * NJ) {
     // two-stage path; workspace: G*NSLICE*CAND floats followed by as many ints (vr2_sample_ws_bytes)
     float* cv = (float*)cand_ws;
@@ -410,7 +492,7 @@ extern "C" int vr2_sample_topk(const void* logits_f32, int64_t ldl, int64_t G, i
                        (const float*)logits_f32, (long)ldl, (int)V, top_k, cv, ci);
     if (vr2_check_launch("vr2_sample_topk(candidates)")) return -2;
     hipLaunchKernelGGL(sample_candidates_kernel, dim3((unsigned)G), dim3(256), 0, (hipStream_t)stream, (const float*)cv,
-                       (const int*)ci, 1.0f / temperature, top_k, (unsigned long long)seed,
+                       (const int*)ci, 1.0f / temperature, top_k, top_p, min_p, (unsigned long long)seed,
                        (const unsigned long long*)seed_dev_u64, (const int*)step_i32, (int*)finished_i32, eos_id, pad_id,
                        (int*)next_ids_i32, (int*)tokens_i32, (long)ldt);
     return vr2_check_launch("vr2_sample_topk(draw)");
@@ -420,6 +502,14 @@ extern "C" int vr2_sample_topk(const void* logits_f32, int64_t ldl, int64_t G, i
                      (const unsigned long long*)seed_dev_u64, (const int*)step_i32,
                      (int*)finished_i32, eos_id, pad_id, (int*)next_ids_i32, (int*)tokens_i32, (long)ldt);
   return vr2_check_launch("vr2_sample_topk");
+}
+
+extern "C" int vr2_sample_topk(const void* logits_f32, int64_t ldl, int64_t G, int64_t V, float temperature, int top_k,
+                               uint64_t seed, const void* seed_dev_u64, const void* step_i32, void* finished_i32,
+                               int eos_id, int pad_id, void* next_ids_i32, void* tokens_i32, int64_t ldt, void* cand_ws,
+                               void* stream) {
+  return vr2_sample_topk_p(logits_f32, ldl, G, V, temperature, top_k, 1.0f, 0.0f, seed, seed_dev_u64, step_i32, finished_i32, eos_id,
+                           pad_id, next_ids_i32, tokens_i32, ldt, cand_ws, stream);
 }
 
 extern "C" int64_t vr2_sample_ws_bytes(int64_t G) { return G * NSLICE * CAND * 8; }

@@ -61,6 +61,7 @@ class PromptState:
     prefix_v: torch.Tensor
     last_hidden: torch.Tensor   # [1][H] f32 residual stream of the last prompt token (pre final norm)
     last_logits: torch.Tensor   # [1][V] f32
+    input_ids: object = None    # host ints [S]: the prompt's token ids (repetition penalty: HF applies it to prompt + generated ids)
 
 
 class Engine:
@@ -500,7 +501,7 @@ class Engine:
         last.copy_(x[S - 1:S])
         logits = self.buf(tag + ".plogits" + slot, (1, t.vocab_size), torch.float32)
         self._logits_rows(W, x[S - 1:S], 1, logits)
-        return PromptState(n_prompt=S, rope_delta=delta, prefix_k=pk, prefix_v=pv, last_hidden=last, last_logits=logits)
+        return PromptState(n_prompt=S, rope_delta=delta, prefix_k=pk, prefix_v=pv, last_hidden=last, last_logits=logits, input_ids=ids)
 
     @_on_stream
     def prefill_batch(self, W: Params, prompts, slots, tag="pol", max_rows=36864):
@@ -570,7 +571,7 @@ class Engine:
         logits = torch.empty((P, V), dtype=torch.float32, device=self.device)
         self._logits_rows(W, lasts, P, logits)
         return [PromptState(n_prompt=len(ids), rope_delta=deltas[p_], prefix_k=slots[p_][0], prefix_v=slots[p_][1],
-                            last_hidden=lasts[p_:p_ + 1], last_logits=logits[p_:p_ + 1]) for p_, ids in enumerate(idss)]
+                            last_hidden=lasts[p_:p_ + 1], last_logits=logits[p_:p_ + 1], input_ids=ids) for p_, ids in enumerate(idss)]
 
     # ------------------------------------------------------------------ decode (K13, K14)
     def prefix_slots(self, n_groups, max_prompt, tag="pol"):
@@ -581,7 +582,7 @@ class Engine:
         bv = self.buf(tag + ".slots_v", (n_groups, t.num_hidden_layers, max_prompt, kv), torch.bfloat16)
         return [(bk[p], bv[p]) for p in range(n_groups)]
 
-    def _decode_step(self, W: Params, st, G, C, bufs, temperature, top_k, seed_dev, eos_id, pad_id):
+    def _decode_step(self, W: Params, st, G, C, bufs, temperature, top_k, seed_dev, eos_id, pad_id, top_p=1.0, min_p=0.0, rep=1.0):
         t = self.cfg.text
         H, hd, nq, nkv, I, V = t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size, t.vocab_size
         nqkv = (nq + 2 * nkv) * hd
@@ -619,7 +620,9 @@ class Engine:
         self._gemv(xn, W, "lm_head", G, logits, 1, prequant=fq)
         # token index step+1 is sampled from the logits of token `step`
         tok1 = bufs["tokens"][:, 1:]
-        lib.call("vr2_sample_topk", logits, logits.stride(0), G, V, temperature, top_k, 0, seed_dev, bufs["step"],
+        if rep != 1.0:    # HF's processors run before its warpers; next_ids still holds the token this step consumed: mark it seen
+            lib.call("vr2_repetition_penalty", logits, logits.stride(0), G, V, rep, bufs["seen"], bufs["seen"].stride(0), bufs["next_ids"], self.s)
+        lib.call("vr2_sample_topk_p", logits, logits.stride(0), G, V, temperature, top_k, top_p, min_p, 0, seed_dev, bufs["step"],
                  bufs["finished"], eos_id, pad_id, bufs["next_ids"], tok1, bufs["tokens"].stride(0), bufs["cand"], self.s)
         lib.call("vr2_add_int", bufs["step"], 1, self.s)
 
@@ -693,12 +696,14 @@ class Engine:
 
     @_on_stream
     def decode(self, W: Params, st, G, max_new_tokens, temperature=0.9, top_k=50, seed=0, eos_token_id=None,
-               use_graph=True, forced_tokens=None, check_every=64):
+               use_graph=True, forced_tokens=None, check_every=64, top_p=1.0, min_p=None, repetition_penalty=1.0):
         """Sample G completions per prompt group of up to max_new_tokens.  ``st``: one PromptState, or a list of P states whose
         prefix KV live in ``prefix_slots`` (P prompt groups decoded together: P*G <= 128 rows per weight pass, so the weights
         are streamed once for all of them).  -> (int32 [P*G, C'] device, buffers).
         eos_token_id=None disables EOS (fixed length).  forced_tokens [P*G,C] (host ints) teacher-forces the inputs
         (the sampled tokens are still produced, from the same logits, for comparison).
+        top_p / min_p / repetition_penalty: HF generate's warpers and processor (grpo_trainer.py:559-570 forwards them); top_p < 1
+        and min_p > 0 need 1 <= top_k <= 64; the penalty covers prompt + generated ids (PromptState.input_ids).
 
         One decode step (all layers + lm_head + sampling) is launch-bound (~260 kernels), so it is captured once per shape
         into a hipGraph; step index, next ids, finished flags, positions and the RNG seed live in device memory so the same
@@ -737,10 +742,28 @@ class Engine:
             b["step"].zero_(); b["finished"].zero_(); b["tokens"].fill_(cfg.pad_token_id)
             b["pos"].copy_(pos0.to(self.device)); b["plen"].copy_(plen.to(self.device))
             seed_dev.fill_(int(seed) & (2**63 - 1))
+            if seen0 is not None:
+                b["seen"].copy_(seen0.to(self.device))
 
-        step_args = (W, None, NG, C, b, temperature, top_k, seed_dev, eos, cfg.pad_token_id)
+        top_p = 1.0 if top_p is None else float(top_p)
+        min_p = 0.0 if min_p is None else float(min_p)
+        rep = 1.0 if repetition_penalty is None else float(repetition_penalty)
+        if (top_p < 1.0 or min_p > 0.0) and not 1 <= int(top_k) <= 64:
+            raise ValueError(f"top_p={top_p} / min_p={min_p} run on the top-k candidate set: they need 1 <= top_k <= 64 (got {top_k})")
+        seen0 = None
+        if rep != 1.0:
+            words = (V + 31) // 32
+            b["seen"] = self.buf("d.seen", (NG, words), torch.int32)
+            bits = np.zeros((NG, words * 32), dtype=bool)
+            for p_, s_ in enumerate(states):
+                if s_.input_ids is None:
+                    raise ValueError("repetition_penalty needs PromptState.input_ids (states from Engine.prefill / prefill_batch)")
+                ids_p = np.asarray(s_.input_ids).reshape(-1)
+                bits[p_ * G:(p_ + 1) * G, ids_p[(ids_p >= 0) & (ids_p < V)]] = True
+            seen0 = torch.from_numpy(np.packbits(bits, axis=1, bitorder="little").view(np.int32).copy())
+        step_args = (W, None, NG, C, b, temperature, top_k, seed_dev, eos, cfg.pad_token_id, top_p, min_p, rep)
         key = (id(W), NG, P, C, cap_s, float(temperature), int(top_k), eos, k0.data_ptr(), pstride, self._ws_epoch, bool(self.decode_fp8),
-               bool(self.decode_fp8_act))
+               bool(self.decode_fp8_act), top_p, min_p, rep)
         graph = None
         if getattr(self, "_graph_epoch", -1) != self._ws_epoch:       # a workspace moved: every captured graph is stale
             for ex_ in self._graphs.values():
@@ -769,7 +792,9 @@ class Engine:
         for p_, s_ in enumerate(states):
             logits0[p_ * G:(p_ + 1) * G].copy_(s_.last_logits.expand(G, V))
         tok0 = b["tokens"]
-        lib.call("vr2_sample_topk", logits0, logits0.stride(0), NG, V, temperature, top_k, (int(seed) * 2654435761 + 12345) & (2**64 - 1),
+        if rep != 1.0:
+            lib.call("vr2_repetition_penalty", logits0, logits0.stride(0), NG, V, rep, b["seen"], b["seen"].stride(0), None, self.s)
+        lib.call("vr2_sample_topk_p", logits0, logits0.stride(0), NG, V, temperature, top_k, top_p, min_p, (int(seed) * 2654435761 + 12345) & (2**64 - 1),
                  None, b["zero"], b["finished"], eos, cfg.pad_token_id, b["next_ids"], tok0, tok0.stride(0), b["cand"], self.s)
         steps_done = 0
         for step in range(C - 1):

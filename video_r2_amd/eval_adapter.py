@@ -150,13 +150,13 @@ class VideoR2EvalModel:
         if (kw.get("num_beams") or 1) != 1:
             raise ValueError(f"num_beams={kw['num_beams']}: the engine samples or decodes greedily, it has no beam search")
         sample = float(kw["temperature"] or 0.0) > 0.0
-        if sample and kw.get("top_p") not in (None, 1.0):
-            raise ValueError(f"top_p={kw['top_p']}: the engine's sampler implements temperature + top-k only")
         idss = [p[0] for p in prepared]
         clips = [p[1] for p in prepared]
         enc = eng.encode_videos([c for cl in clips for c in cl], per_prompt=[len(cl) for cl in clips])
         dec = dict(temperature=float(kw["temperature"]) if sample else 1.0, top_k=int(kw.get("top_k") or 50) if sample else 1,
-                   seed=int(kw.get("seed", 0)), eos_token_id=cfg.eos_token_id)
+                   seed=int(kw.get("seed", 0)), eos_token_id=cfg.eos_token_id,
+                   top_p=(kw.get("top_p") if sample else None), min_p=(kw.get("min_p") if sample else None),
+                   repetition_penalty=kw.get("repetition_penalty") or 1.0)
         if len(prepared) == 1:
             emb, plan = enc[0]
             st = eng.prefill(self._model.text, idss[0], None if emb is None else emb.clone(), plan, prepared[0][2], tag="pol")

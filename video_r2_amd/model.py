@@ -31,6 +31,8 @@ class GenerationConfig:
     temperature: float = 0.9
     top_p: float = 1.0
     top_k: int = 50
+    min_p: float | None = None
+    repetition_penalty: float = 1.0
     pad_token_id: int | None = None
     eos_token_id: int | None = None
     seed: int = 0
@@ -147,9 +149,10 @@ class VideoR2Model:
     def generate(self, input_ids, attention_mask=None, pixel_values_videos=None, video_grid_thw=None,
                  second_per_grid_ts=None, generation_config: GenerationConfig | None = None, **hf_kwargs):
         """Also takes HF ``generate`` keyword arguments in place of a generation_config -- max_new_tokens, do_sample,
-        temperature, top_k, top_p, num_beams, eos_token_id, pad_token_id, use_cache -- which is how the evaluation harness
-        calls its model (/root/reference/eval/lmms-eval/lmms_eval/models/qwen2_5_vl.py:326-336): greedy when do_sample is
-        false, beams and nucleus sampling refused (not silently ignored), image inputs refused (video path only)."""
+        temperature, top_k, top_p, min_p, repetition_penalty, num_beams, eos_token_id, pad_token_id, use_cache -- which is how
+        the evaluation harness calls its model (/root/reference/eval/lmms-eval/lmms_eval/models/qwen2_5_vl.py:326-336): greedy
+        when do_sample is false, beams refused (not silently ignored), image inputs refused (video path only).  top_p / min_p run
+        on the top-k candidate set (1 <= top_k <= 64), the repetition penalty over prompt + generated ids, all in HF's order."""
         if hf_kwargs.get("pixel_values") is not None or hf_kwargs.get("image_grid_thw") is not None:
             raise NotImplementedError("VideoR2Model.generate: image inputs are not supported (video rollout path only)")
         if generation_config is None:
@@ -159,10 +162,11 @@ class VideoR2Model:
                     setattr(gc, k, hf_kwargs[k])
             if hf_kwargs.get("temperature") is not None:
                 gc.temperature = float(hf_kwargs["temperature"])
-            if hf_kwargs.get("top_p") is not None:
-                gc.top_p = float(hf_kwargs["top_p"])
+            for k in ("top_p", "min_p", "repetition_penalty"):
+                if hf_kwargs.get(k) is not None:
+                    setattr(gc, k, float(hf_kwargs[k]))
             if "do_sample" in hf_kwargs and not hf_kwargs["do_sample"]:
-                gc.top_p = 1.0                                   # HF ignores the warpers without sampling
+                gc.top_p, gc.min_p = 1.0, None                   # HF ignores the warpers without sampling
         else:
             gc = generation_config
         if (hf_kwargs.get("num_beams") or 1) != 1:
@@ -179,10 +183,10 @@ class VideoR2Model:
         outs = []
         vid_cursor = 0
         groups = list(_groups(ids, mask, self._same_video_fn(ids, mask, pixel_values_videos, grids, offs)))
-        if gc.top_p not in (None, 1.0):
-            raise ValueError(f"generation_config.top_p={gc.top_p}: the engine's sampler implements temperature + top-k only")
         temp = gc.temperature if gc.do_sample else 1.0
         topk = gc.top_k if gc.do_sample else 1
+        warp = dict(top_p=gc.top_p if gc.do_sample else 1.0, min_p=gc.min_p if gc.do_sample else None,
+                    repetition_penalty=gc.repetition_penalty)    # (the penalty is a processor: HF applies it to greedy decoding too)
         eos = gc.eos_token_id if gc.eos_token_id is not None else cfg.eos_token_id
         uniform = len(groups) > 1 and len({n for _, n, _ in groups}) == 1 and groups[0][1] * 2 <= 128
         if uniform:
@@ -202,7 +206,7 @@ class VideoR2Model:
                         emb = emb.clone()
                     states.append(self.engine.prefill(self.text, ids_row, emb, plan, sec, tag="pol", prefix_out=slots[p_]))
                 toks, _ = self.engine.decode(self.text, states if len(states) > 1 else states[0], n, gc.max_new_tokens,
-                                             temperature=temp, top_k=topk, seed=gc.seed + 7919 * c0, eos_token_id=eos)
+                                             temperature=temp, top_k=topk, seed=gc.seed + 7919 * c0, eos_token_id=eos, **warp)
                 for p_, (row, n_, _) in enumerate(chunk):
                     outs.append((row, n_, toks[p_ * n:(p_ + 1) * n]))
         else:
@@ -213,7 +217,7 @@ class VideoR2Model:
                     _, _, _, vid_cursor = self._skip(ids_row, grids, vid_cursor)
                 st = self.engine.prefill(self.text, ids_row, emb, plan, sec, tag="pol")
                 toks, _ = self.engine.decode(self.text, st, n, gc.max_new_tokens, temperature=temp, top_k=topk,
-                                             seed=gc.seed + 7919 * gi, eos_token_id=eos)
+                                             seed=gc.seed + 7919 * gi, eos_token_id=eos, **warp)
                 outs.append((row, n, toks))
         C = max(t.shape[1] for _, _, t in outs)
         result = torch.full((B, S + C), pad, dtype=torch.long, device=self.device)

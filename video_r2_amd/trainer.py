@@ -91,10 +91,12 @@ class QwenGRPOTrainer:
         self.global_step = 0
         self.num_input_tokens_seen = 0
         self.sentence_model = sentence_model
-        for flag, neutral in (("top_p", 1.0), ("min_p", None), ("repetition_penalty", 1.0)):
-            if getattr(args, flag, neutral) not in (neutral, None if neutral is None else float(neutral)):
-                raise ValueError(f"--{flag} {getattr(args, flag)}: the engine's sampler implements temperature + top-k only "
-                                 f"(the reference recipe leaves {flag} at {neutral}); refusing to ignore it silently")
+        # HF generate's warpers / processor the reference forwards (grpo_trainer.py:559-570): applied by the decode sampler
+        self.sampling = dict(top_p=getattr(args, "top_p", 1.0), min_p=getattr(args, "min_p", None),
+                             repetition_penalty=getattr(args, "repetition_penalty", 1.0))
+        if (self.sampling["top_p"] not in (None, 1.0) or self.sampling["min_p"]) and not 1 <= int(args.top_k or 0) <= 64:
+            raise ValueError(f"--top_p {args.top_p} / --min_p {args.min_p} run on the top-k candidate set: they need 1 <= --top_k <= 64 "
+                             f"(got {args.top_k})")
         self.reducer = vdist.MetricsReducer(device=model.device if vdist.world_size() > 1 and torch.cuda.is_available() else "cpu")
         world = vdist.world_size()
         G = self.num_generations
@@ -189,7 +191,7 @@ class QwenGRPOTrainer:
             states = eng.prefill_batch(m.text, [(ids, emb, plan, sec) for ids, (emb, plan, sec) in zip(idss, encs)], slots, tag="pol")
             toks_all, _ = eng.decode(m.text, states if len(states) > 1 else states[0], G, a.max_completion_length,
                                      temperature=a.temperature, top_k=a.top_k, seed=seed + 7919 * c0,
-                                     eos_token_id=m.cfg.eos_token_id)
+                                     eos_token_id=m.cfg.eos_token_id, **self.sampling)
             new = []
             for p_, (pi, ids) in enumerate(zip(pis, idss)):
                 toks = toks_all[p_ * G:(p_ + 1) * G]
@@ -257,7 +259,7 @@ class QwenGRPOTrainer:
             rollouts, adv = self._buffered
         dev = self.model.device
         eng = self.model.engine
-        losses, metrics = [], defaultdict(list)
+        losses, metrics, outs = [], defaultdict(list), []
         G = self.num_generations
         # a reference micro-batch that spans several groups (per_device_train_batch_size > G) normalises the token-mean losses
         # by ITS token count: group g's share is tokens_g / tokens_block, applied as a scale on that group's loss and gradient
@@ -281,8 +283,10 @@ class QwenGRPOTrainer:
                     out["dlogp"].mul_(scale[i]); out["loss"] = out["loss"] * scale[i]
             if self.update:
                 self.updater.backward(out["dlogp"], exchange=(i == len(rollouts) - 1))   # gradients accumulate over the groups
-            eng.sync()
             ro["dlogp"] = out["dlogp"]
+            outs.append(out)
+        eng.sync()                                                   # ONE host sync for the step's groups: the scalars are read
+        for out in outs:                                             # here, not per group (each read would drain the stream)
             losses.append(out["loss"].item() / len(rollouts))       # Trainer divides by the accumulation count
             if self.beta != 0.0:
                 metrics["kl"].append(out["kl"].item())

@@ -316,15 +316,19 @@ def test_key_work_covers_every_visible_pair_once():
     """vr2_attn_bwd_dkv work list: every (key row, query row, q head of the GQA group) the causal / shared-prefix mask allows is
     walked by exactly one item, whatever the cuts by query range and by heads; heaviest items come first."""
     from video_r2_amd.host import vision_plan as vp
-    for (S, G, C, kt, qs, group, ms) in ((70, 2, 40, 128, 48, 2, 3), (300, 3, 200, 128, 256, 7, 8), (130, 2, 64, 64, 64, 4, 64), (1, 1, 1, 128, 512, 7, 64)):
-        T = S + G * C
+    for (S, G, C, kt, qs, group, ms, lens) in ((70, 2, 40, 128, 48, 2, 3, None), (300, 3, 200, 128, 256, 7, 8, None), (130, 2, 64, 64, 64, 4, 64, None),
+                                               (1, 1, 1, 128, 512, 7, 64, None),
+                                               (70, 3, 40, 128, 48, 2, 3, [40, 7, 0]), (300, 3, 200, 128, 256, 7, 8, [129, 200, 1])):   # packed ragged rows
+        ln = [C] * G if lens is None else lens
+        T = S + sum(ln)
         allow = np.zeros((T, T), dtype=bool)                         # [query][key]
         allow[:S, :S] = np.tril(np.ones((S, S), dtype=bool))
+        a = S
         for g in range(G):
-            a = S + g * C
-            allow[a:a + C, :S] = True
-            allow[a:a + C, a:a + C] = np.tril(np.ones((C, C), dtype=bool))
-        kw = vp.key_work(S, G, C, k_tile=kt, q_split=qs, group=group, max_steps=ms)
+            allow[a:a + ln[g], :S] = True
+            allow[a:a + ln[g], a:a + ln[g]] = np.tril(np.ones((ln[g], ln[g]), dtype=bool))
+            a += ln[g]
+        kw = vp.key_work(S, G, C, k_tile=kt, q_split=qs, group=group, max_steps=ms, lens=lens)
         assert kw.dtype == np.int32 and kw.shape[1] == 8 and (kw[:, 1] <= 128).all() and (kw[:, 1] >= 1).all()
         seen = np.zeros((group, T, T), dtype=np.int32)
         steps = []

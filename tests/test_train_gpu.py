@@ -151,3 +151,47 @@ def test_optimizer_step_matches_torch_adamw_and_changes_the_policy():
     d = ((lp1 - lp0) * m).sum(1)
     assert d[0].item() > 0 and d[1].item() < 0
     assert cosine_lr(1e-6, 0, 100) == 1e-6 and abs(cosine_lr(1e-6, 50, 100) - 5e-7) < 1e-12 and cosine_lr(1e-6, 100, 100) < 1e-12
+
+
+@pytest.mark.parametrize("group,lens", [(2, [10, 7, 1]), (7, [3, 0, 10])])
+def test_packed_completions_equal_the_padded_layout(group, lens):
+    """Completions cut at their first EOS are scored and trained on as PACKED rows (Engine.score / Trainer.forward with lens=):
+    sum(lens) rows instead of G x C.  A row's arithmetic does not depend on which other rows share its launch, so the log-probs
+    of the kept positions equal the padded layout's (bit for bit in the GEMMs; the attention tiles start at the sequence's own
+    first row either way), the skipped positions read 0, and with the loss gradient zero behind each EOS the weight gradients of
+    the two layouts agree to fp32 summation order (the token dimension is the GEMMs' k)."""
+    from video_r2_amd.train import Trainer
+    ocfg, eng, w, cfg, px, grid, prompt, comp = _setup(group, 70 + group)
+    G, C = comp.shape
+    lens = np.asarray(lens)
+    valid = torch.from_numpy(np.arange(C)[None, :] < lens[:, None])
+    emb, plan = eng.encode_video(torch.from_numpy(px).to(eng.device), [grid])
+    st = eng.prefill(eng.text, prompt, emb, plan, [1.0])
+    dense = eng.score(eng.text, st, comp, 0.9).cpu().clone()
+    packed = eng.score(eng.text, st, comp, 0.9, lens=lens).cpu().clone()
+    assert torch.equal(packed[~valid], torch.zeros_like(packed[~valid]))
+    assert (packed[valid] - dense[valid]).abs().max().item() <= 1e-5
+    full = torch.cat([torch.from_numpy(np.repeat(prompt[None], G, 0)), comp], 1)
+    want = om.per_token_logps(w, ocfg, full, np.ones_like(full.numpy()), C, 0.9, pixel_values_videos=torch.from_numpy(np.tile(px, (G, 1))),
+                              video_grid_thw=np.asarray([grid] * G), second_per_grid_ts=[1.0] * G)
+    r = rel_err(packed.numpy(), want.numpy())[valid.numpy()]
+    assert r.max() < 2e-3, r.max()
+    assert torch.equal(eng.score(eng.text, st, comp, 0.9, lens=[C] * G).cpu(), dense)     # full lengths = the dense layout
+    assert float(eng.score(eng.text, st, comp, 0.9, lens=[0] * G).abs().max()) == 0
+    # training forward + backward, packed against padded with the same (masked) loss gradient
+    tr = Trainer(eng, eng.text)
+    gen = torch.Generator().manual_seed(3)
+    dl = (torch.randn(G, C, generator=gen) * valid).to(eng.device)
+    lp_d = tr.forward(prompt, emb, plan, [1.0], comp, 0.9).cpu().clone()
+    tr.backward(dl)
+    eng.sync()
+    g_d = {k: v.clone() for k, v in tr.state.grad.items()}
+    tr.state.zero_grad()
+    lp_p = tr.forward(prompt, emb, plan, [1.0], comp, 0.9, lens=lens).cpu().clone()
+    tr.backward(dl)
+    eng.sync()
+    assert torch.equal(lp_p[~valid], torch.zeros_like(lp_p[~valid]))
+    assert (lp_p[valid] - lp_d[valid]).abs().max().item() <= 1e-5
+    for k, gd in g_d.items():
+        e = (tr.state.grad[k] - gd).norm().item() / max(gd.norm().item(), 1e-20)
+        assert e < 2e-3, (k, e)

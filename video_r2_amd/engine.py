@@ -813,44 +813,85 @@ class Engine:
         return b["tokens"][:, :n_tok].clone(), b     # clone: the workspace is reused by the next call
 
     # ------------------------------------------------------------------ teacher-forced log-probs (K15)
+    @staticmethod
+    def ragged_layout(G, C, lens):
+        """Completions cut at their own lengths, packed back to back: lens[g] <= C rows for sequence g.  -> dict(lens, offs (row
+        of each sequence's first token in the packed space), R (total rows), sel (int64 [R]: packed row -> flat index g*C + j of
+        the padded [G, C] layout), first (int64: packed rows with j == 0), src (int64 [R]: packed row whose hidden state PREDICTS
+        this row's token, i.e. row - 1; -1 for j == 0: the prompt's last row))."""
+        lens = np.asarray(lens, dtype=np.int64).reshape(-1)
+        if lens.shape[0] != G or (lens < 0).any() or (lens > C).any():
+            raise ValueError(f"lens must hold one length in [0, {C}] per sequence, got {lens.tolist()}")
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        R = int(lens.sum())
+        sel = np.concatenate([g * C + np.arange(lens[g]) for g in range(G)]) if R else np.zeros(0, dtype=np.int64)
+        src = np.arange(R, dtype=np.int64) - 1
+        first = offs[lens > 0]
+        src[first] = -1
+        return dict(lens=lens, offs=offs, R=R, sel=sel.astype(np.int64), first=first.astype(np.int64), src=src)
+
     @_on_stream
-    def score(self, W: Params, st: PromptState, completion_ids, temperature, tag="pol", row_chunk=1024, return_logits=False):
+    def score(self, W: Params, st: PromptState, completion_ids, temperature, tag="pol", row_chunk=1024, return_logits=False, lens=None):
         """completion_ids int [G,C] -> per-token log-probs f32 [G,C] (device) of ``_get_per_token_logps``.
 
         Row (g,j) of the lm_head input is the hidden state that PREDICTS completion token j: the prompt's last token for
         j=0 (shared by all g), completion token j-1 otherwise.  Completion rows attend the shared prompt prefix KV plus
-        their own causal prefix."""
+        their own causal prefix.
+        lens (host ints, one per sequence): only the first lens[g] tokens of sequence g are scored -- the rows behind a
+        completion's first EOS are masked out of the loss (grpo_trainer.py:793-806), so they are not computed at all: the
+        sequences are packed back to back (sum(lens) rows instead of G*C) and the skipped positions read 0."""
         cfg, t = self.cfg, self.cfg.text
         comp = torch.as_tensor(np.asarray(completion_ids) if not torch.is_tensor(completion_ids) else completion_ids)
         comp = comp.to(device=self.device, dtype=torch.int32).contiguous()
         G, C = comp.shape
         H, hd, nkv, V = t.hidden_size, t.head_dim, t.num_key_value_heads, t.vocab_size
-        T = G * C
         S = st.n_prompt
+        if lens is not None and int(np.asarray(lens).sum()) == G * C:
+            lens = None                                           # nothing to cut: the dense layout
+        if lens is None:
+            T = G * C
+            flat_tok = comp.view(-1)
+            p1 = (np.arange(C, dtype=np.int64) + S + st.rope_delta)
+            pos1 = np.tile(p1, G)
+            works = [vp.causal_work(C, g * C, 0, S, g * C, q_tile=vp.LM_Q_TILE) for g in range(G)]
+            lay = None
+        else:
+            if return_logits:
+                raise ValueError("return_logits needs the dense layout (lens=None)")
+            lay = self.ragged_layout(G, C, lens)
+            T = lay["R"]
+            if T == 0:
+                return torch.zeros((G, C), dtype=torch.float32, device=self.device)
+            d_sel = torch.from_numpy(lay["sel"]).to(self.device)
+            flat_tok = comp.view(-1).index_select(0, d_sel).contiguous()
+            pos1 = np.concatenate([np.arange(n, dtype=np.int64) + S + st.rope_delta for n in lay["lens"]])
+            works = [vp.causal_work(int(n), int(o), 0, S, int(o), q_tile=vp.LM_Q_TILE) for n, o in zip(lay["lens"], lay["offs"]) if n > 0]
         x = self.buf(tag + ".sx", (T, H), torch.float32)
-        lib.call("vr2_embed_rows", comp, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, self.s)
+        lib.call("vr2_embed_rows", flat_tok, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, self.s)
         # positions of completion token j: S + j + rope_delta on all three axes
-        p1 = (np.arange(C, dtype=np.int64) + S + st.rope_delta)
-        pos = np.broadcast_to(np.tile(p1, G)[None, :], (3, T))
+        pos = np.broadcast_to(pos1[None, :], (3, T))
         d_pos = _i32(pos, self.device)
         cos = self.buf(tag + ".scos", (T, hd // 2), torch.float32)
         sin = self.buf(tag + ".ssin", (T, hd // 2), torch.float32)
         lib.call("vr2_mrope_table", d_pos, T, self.inv_freq, self.section, cos, sin, hd, self.s)
         ks = self.buf(tag + ".sk", (T, nkv * hd), torch.bfloat16)
         vs = self.buf(tag + ".sv", (T, nkv * hd), torch.bfloat16)
-        work = vp.heaviest_first(np.concatenate([vp.causal_work(C, g * C, 0, S, g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0))
+        work = vp.heaviest_first(np.concatenate(works, 0))
         d_work = _i32(work, self.device)
         self._lm_rows(W, x, T, cos, sin, d_work, st.prefix_k, st.prefix_v, ks, vs, 0, tag + ".s")
         # shift: hs[(g,0)] = prompt last hidden ; hs[(g,j)] = x[(g,j-1)]
         hs = self.buf(tag + ".shs", (T, H), torch.float32)
         with torch.cuda.stream(self.stream):
-            hv, xv = hs.view(G, C, H), x.view(G, C, H)
-            hv[:, 1:].copy_(xv[:, :-1])
-            hv[:, 0].copy_(st.last_hidden.expand(G, H))
+            if lay is None:
+                hv, xv = hs.view(G, C, H), x.view(G, C, H)
+                hv[:, 1:].copy_(xv[:, :-1])
+                hv[:, 0].copy_(st.last_hidden.expand(G, H))
+            else:
+                torch.index_select(x, 0, torch.from_numpy(np.maximum(lay["src"], 0)).to(self.device), out=hs)
+                hs.index_copy_(0, torch.from_numpy(lay["first"]).to(self.device), st.last_hidden.expand(len(lay["first"]), H))
         logp = self.buf(tag + ".slogp", (T,), torch.float32)
         rc = min(row_chunk, T)
         lg = self.buf("lm.chunk_logits", (rc, V), torch.float32)
-        flat_tok = comp.view(-1)
         keep = [] if return_logits else None
         for r0 in range(0, T, rc):
             n = min(rc, T - r0)
@@ -859,6 +900,11 @@ class Engine:
             if return_logits:
                 with torch.cuda.stream(self.stream):
                     keep.append(lg[:n].clone())
+        if lay is not None:
+            with torch.cuda.stream(self.stream):
+                out = torch.zeros(G * C, dtype=torch.float32, device=self.device)
+                out.index_copy_(0, d_sel, logp)
+            return out.view(G, C)
         out = logp.view(G, C)
         if return_logits:
             return out, torch.cat(keep, 0).view(G, C, V)

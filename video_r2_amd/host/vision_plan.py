@@ -88,15 +88,19 @@ def heaviest_first(work):
     return w[np.argsort(-keys, kind="stable")]
 
 
-def key_work(n_prompt, n_seq, n_comp, k_tile=128, q_split=512, group=1, max_steps=64):
+def key_work(n_prompt, n_seq, n_comp, k_tile=128, q_split=512, group=1, max_steps=64, lens=None):
     """Key-centric work items (vr2_attn_bwd_dkv) for the unified row space [prompt rows | seq 0 rows | seq 1 rows | ...]:
     a prompt key tile (k_tile <= 128 rows) is seen by the prompt rows from its first row on (causal) and by EVERY completion
     row; a completion key tile by the later rows of its own sequence (causal).  The all-visible range (n_seq * n_comp rows) is
     cut into q_split-row pieces, and an item that would still walk more than max_steps (q head, 64-row query tile) steps is cut
     again by q heads of the GQA group (`group` heads per KV head), so that no workgroup runs much longer than the others; the
     pieces add into the same fp32 dK/dV rows.  Heaviest items first (the grid is dispatched in order).
+    lens (optional, one per sequence, <= n_comp): sequence g owns lens[g] rows, packed back to back (completions cut at
+    their first EOS: the rows behind it are never computed).
     int32 [n,8]: k_row0, nk, q1_row0, q1_len, q2_row0, q2_len, head0, nheads."""
     assert 1 <= k_tile <= 128
+    lens = [n_comp] * n_seq if lens is None else [int(x) for x in lens]
+    assert len(lens) == n_seq and all(0 <= x <= n_comp for x in lens)
     items = []
 
     def add(k0, nk, q1r, q1l, q2r, q2l):
@@ -109,17 +113,18 @@ def key_work(n_prompt, n_seq, n_comp, k_tile=128, q_split=512, group=1, max_step
             items.append((tiles * nh, (k0, nk, q1r, q1l, q2r, q2l, h0, nh)))
             h0 += nh
 
-    total_c = n_seq * n_comp
+    total_c = sum(lens)
     for k0 in range(0, n_prompt, k_tile):
         nk = min(k_tile, n_prompt - k0)
         add(k0, nk, k0, n_prompt - k0, 0, 0)
         for c0 in range(0, total_c, q_split):
             add(k0, nk, 0, 0, n_prompt + c0, min(q_split, total_c - c0))
+    base = n_prompt
     for g in range(n_seq):
-        base = n_prompt + g * n_comp
-        for k0 in range(0, n_comp, k_tile):
-            nk = min(k_tile, n_comp - k0)
-            add(base + k0, nk, base + k0, n_comp - k0, 0, 0)
+        for k0 in range(0, lens[g], k_tile):
+            nk = min(k_tile, lens[g] - k0)
+            add(base + k0, nk, base + k0, lens[g] - k0, 0, 0)
+        base += lens[g]
     items.sort(key=lambda it: -it[0])
     return np.asarray([it[1] for it in items], dtype=np.int32).reshape(-1, 8)
 

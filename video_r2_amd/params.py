@@ -97,6 +97,8 @@ class GRPOArguments:
                                       # "rank": over all completions a rank holds (round-1 behaviour of this engine)
     decode_weights: str = "bf16"     # "fp8": rollout decode on per-channel e4m3 weight copies and (above 16 rows) per-row e4m3 activations
                                       # on the fp8 MFMA (BASELINE config 5); "fp8w": weight-only fp8
+    pack_completions: bool = True    # score / train on each completion up to its first EOS only (rows behind it are masked out of the
+                                      # loss anyway): sum of lengths rows per group instead of G x max length
     async_rewards: bool = True        # reward functions run on a background thread behind the reference-model scoring
     reward_workers: int = 4           # each reward function scores this many slices of the step's completions concurrently (1 = one call)
     ignored: dict = field(default_factory=dict)

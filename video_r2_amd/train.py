@@ -138,7 +138,10 @@ class Trainer:
 
     # ------------------------------------------------------------------ forward with saved activations
     @_on_stream
-    def forward(self, prompt_ids, video_embeds, plan, second_per_grid_ts, completion_ids, temperature):
+    def forward(self, prompt_ids, video_embeds, plan, second_per_grid_ts, completion_ids, temperature, lens=None):
+        """lens (host ints, one per sequence): train on the first lens[g] tokens of completion g only -- the rows behind a
+        completion's first EOS carry no loss (grpo_trainer.py:793-806) and, being causal successors, influence no other row, so
+        they are left out of the row space: T = S + sum(lens) rows instead of S + G*C, log-probs 0 at the skipped positions."""
         eng, W, cfg = self.eng, self.text, self.eng.cfg
         t = cfg.text
         H, hd, nq, nkv, I, V, L = t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size, t.vocab_size, t.num_hidden_layers
@@ -148,13 +151,23 @@ class Trainer:
         S = int(ids.shape[0])
         comp = torch.as_tensor(completion_ids).to(device=eng.device, dtype=torch.int32).contiguous()
         G, C = comp.shape
-        T = S + G * C
+        if lens is not None and int(np.asarray(lens).sum()) == G * C:
+            lens = None                                           # nothing to cut: the dense layout
+        lay = None if lens is None else Engine.ragged_layout(G, C, lens)
+        if lay is not None and lay["R"] == 0:
+            raise ValueError("forward(): every completion has length 0 -- nothing to train on")
+        R = G * C if lay is None else lay["R"]
+        seq_len = [C] * G if lay is None else [int(n) for n in lay["lens"]]
+        seq_off = [g * C for g in range(G)] if lay is None else [int(o) for o in lay["offs"]]    # first row of a sequence, from S
+        T = S + R
         grids = [] if plan is None else plan.grid_thw
         pos, delta = ri.rope_index_1seq(ids, cfg.video_token_id, cfg.image_token_id, grids, second_per_grid_ts,
                                         merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
-        p1 = np.arange(C, dtype=np.int64) + S + delta
-        pos_all = np.concatenate([pos, np.broadcast_to(np.tile(p1, G)[None, :], (3, G * C))], 1)
-        all_ids = torch.cat([_i32(ids, eng.device), comp.view(-1)])
+        pc = np.concatenate([np.arange(n, dtype=np.int64) + S + delta for n in seq_len])
+        pos_all = np.concatenate([pos, np.broadcast_to(pc[None, :], (3, R))], 1)
+        d_sel = None if lay is None else torch.from_numpy(lay["sel"]).to(eng.device)
+        tok = comp.view(-1) if lay is None else comp.view(-1).index_select(0, d_sel).contiguous()
+        all_ids = torch.cat([_i32(ids, eng.device), tok])
         b = eng.buf
         x = b("t.x", (T, H), torch.float32)
         lib.call("vr2_embed_rows", all_ids, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, eng.s)
@@ -167,9 +180,9 @@ class Trainer:
         cos = b("t.cos", (T, hd // 2), torch.float32); sin = b("t.sin", (T, hd // 2), torch.float32)
         lib.call("vr2_mrope_table", _i32(pos_all, eng.device), T, eng.inv_freq, eng.section, cos, sin, hd, eng.s)
         work = vp.heaviest_first(np.concatenate([vp.causal_work(S, 0, 0, 0, 0, q_tile=vp.LM_Q_TILE)] +
-                                                [vp.causal_work(C, S + g * C, 0, S, S + g * C, q_tile=vp.LM_Q_TILE) for g in range(G)], 0))
+                                                [vp.causal_work(n, S + o, 0, S, S + o, q_tile=vp.LM_Q_TILE) for n, o in zip(seq_len, seq_off) if n > 0], 0))
         d_work = _i32(work, eng.device)
-        kwork = _i32(vp.key_work(S, G, C, group=t.group), eng.device)
+        kwork = _i32(vp.key_work(S, G, C, group=t.group, lens=None if lay is None else seq_len), eng.device)
         sv = dict(x_in=b("t.x_in", (L, T, H), torch.float32), xn1=b("t.xn1", (L, T, H), torch.bfloat16),
                   q=b("t.q", (L, T, nq * hd), torch.bfloat16), k=b("t.k", (L, T, nkv * hd), torch.bfloat16),
                   v=b("t.v", (L, T, nkv * hd), torch.bfloat16), att=b("t.att", (L, T, nq * hd), torch.bfloat16),
@@ -199,11 +212,15 @@ class Trainer:
                      ngu, kgu, eng.s)
             self._gemm(act, f"l{l}.down_w", None, x, T, EPI_ADD_F32)
         # log-prob head: row (g, j) is predicted by the prompt's last row (j == 0) or completion row (g, j-1)
-        R = G * C
         hs = b("t.hs", (R, H), torch.float32)
-        hv, xc = hs.view(G, C, H), x[S:].view(G, C, H)
-        hv[:, 1:].copy_(xc[:, :-1])
-        hv[:, 0].copy_(x[S - 1:S].expand(G, H))
+        pred = None
+        if lay is None:
+            hv, xc = hs.view(G, C, H), x[S:].view(G, C, H)
+            hv[:, 1:].copy_(xc[:, :-1])
+            hv[:, 0].copy_(x[S - 1:S].expand(G, H))
+        else:   # packed rows: row r of the head reads row S + r - 1 of x; a sequence's first row reads the prompt's last row
+            pred = torch.from_numpy(np.where(lay["src"] < 0, S - 1, S + lay["src"])).to(eng.device)
+            torch.index_select(x, 0, pred, out=hs)
         hn = b("t.hn", (R, H), torch.bfloat16)
         eng._norm(hs, W["norm"], hn, R, H, t.rms_norm_eps)
         logp = b("t.logp", (R,), torch.float32)
@@ -214,16 +231,20 @@ class Trainer:
         keep = R * V * 4 <= self.KEEP_LOGITS_BYTES
         lg_all = b("t.logits", (R, V), torch.float32) if keep else None
         lg = None if keep else b("lm.chunk_logits", (rc, V), torch.float32)
-        tok = comp.view(-1)
         for r0 in range(0, R, rc):
             n = min(rc, R - r0)
             if keep:
                 lg = lg_all[r0:r0 + n]
             self._gemm(hn[r0:r0 + n], "lm_head", None, lg, n, EPI_F32)
             lib.call("vr2_lse_gather", lg, lg.stride(0), n, V, tok[r0:r0 + n], temperature, logp[r0:r0 + n], lse_out[r0:r0 + n], eng.s)
-        self._saved = dict(logits=lg_all, sv=sv, S=S, G=G, C=C, T=T, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
-                           lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None)
-        return logp.view(G, C)
+        self._saved = dict(logits=lg_all, sv=sv, S=S, G=G, C=C, T=T, R=R, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
+                           lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None, sel=d_sel, pred=pred,
+                           first=None if lay is None else torch.from_numpy(lay["first"]).to(eng.device))
+        if lay is None:
+            return logp.view(G, C)
+        out = torch.zeros(G * C, dtype=torch.float32, device=eng.device)
+        out.index_copy_(0, d_sel, logp)
+        return out.view(G, C)
 
     # ------------------------------------------------------------------ backward (accumulates into TrainState.grad)
     @_on_stream
@@ -238,10 +259,11 @@ class Trainer:
         H, hd, nq, nkv, I, V, L = t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size, t.vocab_size, t.num_hidden_layers
         I16 = (I + 15) // 16 * 16
         nqkv = (nq + 2 * nkv) * hd
-        S, G, C, T, sv = s["S"], s["G"], s["C"], s["T"], s["sv"]
-        R = G * C
+        S, G, C, T, R, sv = s["S"], s["G"], s["C"], s["T"], s["R"], s["sv"]
         b = eng.buf
         dl = dlogp.reshape(-1).to(torch.float32).contiguous()
+        if s["sel"] is not None:
+            dl = dl.index_select(0, s["sel"]).contiguous()          # packed rows: the gradient of the positions that were computed
         # ---- log-prob head
         Vp = W.shape["lm_head_t"][1]
         rc = min(4096, R)        # rows per logits chunk: 4096 x 152064 fp32 = 2.5 GB; keeps the head GEMMs on 256-row tiles
@@ -266,9 +288,13 @@ class Trainer:
             self._exchange("head")
         dx = b("t.dx", (T, H), torch.float32)
         dx.zero_()
-        dv_, dc = dhs.view(G, C, H), dx[S:].view(G, C, H)
-        dc[:, :-1].copy_(dv_[:, 1:])
-        dx[S - 1].copy_(dv_[:, 0].sum(0))
+        if s["sel"] is None:
+            dv_, dc = dhs.view(G, C, H), dx[S:].view(G, C, H)
+            dc[:, :-1].copy_(dv_[:, 1:])
+            dx[S - 1].copy_(dv_[:, 0].sum(0))
+        else:   # head row r came from x row pred[r]: unique rows except the prompt's last one, which fed every sequence's first row
+            dx.index_copy_(0, s["pred"], dhs)
+            dx[S - 1].copy_(dhs.index_select(0, s["first"]).sum(0))
         dxb = b("t.dxb", (T, H), torch.bfloat16)
         dact = b("t.dact", (T, I16), torch.bfloat16)
         dgu = b("t.dgu", (T, 2 * I16), torch.bfloat16)

@@ -197,7 +197,10 @@ class QwenGRPOTrainer:
                 toks = toks_all[p_ * G:(p_ + 1) * G]
                 mask, eos_idx, any_eos = hg.completion_mask(toks, m.cfg.eos_token_id, a.mask_truncated_completions)
                 emb, plan, sec = encs[p_]
-                new.append(dict(prompt_ids=ids, completion_ids=toks, completion_mask=mask, any_eos=any_eos, logps=None,
+                # completions are scored and trained on up to their first EOS only: the rows behind it carry no loss (the mask
+                # above) and influence nothing before them, so the scoring / training passes pack the sequences at these lengths
+                lens = mask.sum(1).cpu().numpy() if getattr(a, "pack_completions", True) else None
+                new.append(dict(prompt_ids=ids, completion_ids=toks, completion_mask=mask, any_eos=any_eos, logps=None, lens=lens,
                                 ref_logps=None, decode=pi.get("decode"), emb=emb, plan=plan, sec=sec, _state=states[p_]))
             groups.extend(new)
             last = c0 + per >= len(examples)
@@ -213,11 +216,11 @@ class QwenGRPOTrainer:
                 ref_states = eng.prefill_batch(self.ref_params, [(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"]) for ro in new], ref_slots, tag="ref")
             for k_, ro in enumerate(new):   # scoring while the chunk's prefix caches are still in place
                 if self.beta != 0.0:
-                    ro["ref_logps"] = eng.score(self.ref_params, ref_states[k_], ro["completion_ids"], a.temperature, tag="ref")
+                    ro["ref_logps"] = eng.score(self.ref_params, ref_states[k_], ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"])
                     if len(examples) > 1:
                         ro["ref_logps"] = ro["ref_logps"].clone()  # the scoring output is a reused workspace
                 if not self.update:
-                    ro["logps"] = eng.score(m.text, ro["_state"], ro["completion_ids"], a.temperature, tag="pol")
+                    ro["logps"] = eng.score(m.text, ro["_state"], ro["completion_ids"], a.temperature, tag="pol", lens=ro["lens"])
                     if len(examples) > 1:
                         ro["logps"] = ro["logps"].clone()
                 ro.pop("_state")
@@ -253,7 +256,7 @@ class QwenGRPOTrainer:
             if a.num_iterations > 1:
                 for ro in rollouts:      # old-policy log-probs, fixed for the iterations that re-use this rollout
                     st = self.model.engine.prefill(self.model.text, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], tag="pol")
-                    ro["old_logps"] = self.model.engine.score(self.model.text, st, ro["completion_ids"], a.temperature, tag="old").clone()
+                    ro["old_logps"] = self.model.engine.score(self.model.text, st, ro["completion_ids"], a.temperature, tag="old", lens=ro["lens"]).clone()
             self._buffered = (rollouts, adv)
         else:
             rollouts, adv = self._buffered
@@ -272,8 +275,12 @@ class QwenGRPOTrainer:
                 for g in blk:
                     scale[g] = max(ntok[g], 1.0) / tot * len(blk)
         for i, ro in enumerate(rollouts):
-            if self.update:      # policy log-probs WITH saved activations (the forward of grpo_trainer.py:1094-1096)
-                ro["logps"] = self.updater.forward(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"], a.temperature)
+            live = ro["lens"] is None or int(ro["lens"].sum()) > 0       # (a group whose completions are all masked out has no rows)
+            if self.update and live:      # policy log-probs WITH saved activations (the forward of grpo_trainer.py:1094-1096)
+                ro["logps"] = self.updater.forward(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"], a.temperature,
+                                                   lens=ro["lens"])
+            elif self.update:
+                ro["logps"] = torch.zeros(ro["completion_ids"].shape, dtype=torch.float32, device=dev)
             with torch.cuda.stream(eng.stream):
                 out = hg.grpo_loss(ro["logps"], ro["completion_mask"], adv["advantages"][i * G:(i + 1) * G].to(dev),
                                    ref_logps=ro["ref_logps"], old_logps=ro.get("old_logps"), beta=self.beta, epsilon_low=self.epsilon_low,
@@ -281,7 +288,7 @@ class QwenGRPOTrainer:
                                    max_completion_length=a.max_completion_length, norm_rows=self.norm_rows, stream=eng.s)
                 if scale[i] != 1.0:
                     out["dlogp"].mul_(scale[i]); out["loss"] = out["loss"] * scale[i]
-            if self.update:
+            if self.update and live:
                 self.updater.backward(out["dlogp"], exchange=(i == len(rollouts) - 1))   # gradients accumulate over the groups
             ro["dlogp"] = out["dlogp"]
             outs.append(out)

@@ -65,6 +65,11 @@ def parse():
                         "engine work (runs without a GPU; tests/test_bench_launch.py)")
     p.add_argument("--no-recipe-shape", action="store_true",
                    help="skip the extra untimed steps at ONE prompt group per GPU (the reference recipe's per-device shape)")
+    p.add_argument("--eos-mix", default="uniform:128:1024",
+                   help="one extra, separately reported step pair with EOS-terminated completions emulated (random-init weights "
+                        "never emit EOS): sequence lengths drawn uniform:LO:HI per sequence (seeded); the decode stops at the "
+                        "longest one (rounded up to the engine's 64-step EOS check) and the scoring / training passes run on the "
+                        "packed rows.  'off' skips it.  Never part of `value`.")
     p.add_argument("--prompts-per-gpu", type=int, default=16,
                    help="prompt groups per GPU per optimiser step (the reference's per_device_train_batch_size x "
                         "gradient_accumulation_steps); groups are decoded together, P*G <= 128 rows per weight pass")
@@ -263,11 +268,13 @@ def main():
     ref_slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="ref")
     torch.cuda.synchronize()
 
-    def step(i, rec=None, mine=None):
-        """One GRPO step over this rank's P prompt groups.  rec(name) marks a phase boundary (instrumented extra step only)."""
+    def step(i, rec=None, mine=None, lens=None):
+        """One GRPO step over this rank's P prompt groups.  rec(name) marks a phase boundary (instrumented extra step only).
+        lens (host ints, one per sequence): emulated EOS positions -- see --eos-mix."""
         mark = rec if rec is not None else (lambda name: None)
         mine = prompts[i * P:(i + 1) * P] if mine is None else mine
         Pn = len(mine)
+        Cd = C if lens is None else min(C, -(-int(lens.max()) // 64) * 64)     # the decode checks for "all finished" every 64 steps
         # the step's P clips go through the vision tower in ONE pass and its P prompts through ONE policy prefill and ONE
         # reference prefill (M = P x 4096 patches / P x S tokens: every projection runs on full 256-row tiles)
         mark(None)
@@ -275,7 +282,7 @@ def main():
         mark("vit")
         states = eng.prefill_batch(pol, [(ids, enc[p_][0], enc[p_][1], [1.0]) for p_, (_, _, ids) in enumerate(mine)], slots[:Pn], tag="pol")
         mark("prefill")
-        toks_all, _ = eng.decode(pol, states, G, C, temperature=0.9, top_k=50, seed=1000 * rank + i, eos_token_id=None,
+        toks_all, _ = eng.decode(pol, states, G, Cd, temperature=0.9, top_k=50, seed=1000 * rank + i, eos_token_id=None,
                                  use_graph=not a.no_graph)
         mark("decode")
         eng.sync()
@@ -289,12 +296,16 @@ def main():
             emb, plan = enc[p_]
             toks = toks_all[p_ * G:(p_ + 1) * G]
             mark(None)
-            lp_ref = eng.score(ref, ref_states[p_], toks, 0.9, tag="ref")
+            ln = None if lens is None else np.minimum(lens[p_ * G:(p_ + 1) * G], Cd)
+            lp_ref = eng.score(ref, ref_states[p_], toks, 0.9, tag="ref", lens=ln)
             mark("ref_prefill+ref_score")
-            lp = eng.score(pol, states[p_], toks, 0.9, tag="pol") if upd is None else upd.forward(ids, emb, plan, [1.0], toks, 0.9)
+            lp = (eng.score(pol, states[p_], toks, 0.9, tag="pol", lens=ln) if upd is None
+                  else upd.forward(ids, emb, plan, [1.0], toks, 0.9, lens=ln))
             mark("policy_forward")
             with torch.cuda.stream(eng.stream):
                 mask, _, _ = hg.completion_mask(toks, -1)
+                if ln is not None:
+                    mask = (torch.arange(Cd, device=device)[None, :] < torch.from_numpy(ln).to(device)[:, None]).int()
                 adv = hg.group_advantages(rew_all[p_ * G:(p_ + 1) * G], [1.0], G, loss_type="bnpo")["advantages"]
                 out = hg.grpo_loss(lp, mask, adv, ref_logps=lp_ref, beta=0.04, loss_type="bnpo", stream=eng.s)
             if upd is not None:
@@ -351,6 +362,31 @@ def main():
             tr = torch.tensor([recipe], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tr, op=dist.ReduceOp.MAX)
             recipe = float(tr.item())
+
+    # ---- EOS-terminated completions, emulated (--eos-mix): the same step with per-sequence lengths; the decode stops at the
+    # longest sequence and the scoring / training passes run on packed rows.  Untimed for `value`; reported beside it.
+    eos_mix = None
+    if a.eos_mix and a.eos_mix != "off":
+        kind, lo, hi = a.eos_mix.split(":")
+        assert kind == "uniform", "--eos-mix uniform:LO:HI"
+        rng = np.random.default_rng(99 + rank)
+        lens_a = rng.integers(int(lo), min(int(hi), C) + 1, size=P * G)
+        lens_b = rng.integers(int(lo), min(int(hi), C) + 1, size=P * G)
+        step(0, lens=lens_a)                                   # captures the decode graph of the shorter token budget
+        barrier()
+        t1 = time.perf_counter()
+        step(1, lens=lens_b)
+        barrier()
+        em = time.perf_counter() - t1
+        if world > 1:
+            import torch.distributed as dist
+            te = torch.tensor([em], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            em = float(te.item())
+        eos_mix = {"lengths": f"uniform {lo}..{min(int(hi), C)} tokens per sequence (seeded), mean {float(lens_b.mean()):.0f}, longest {int(lens_b.max())}",
+                   "samples_per_s": G * P * world / em, "ms_per_step": em * 1e3,
+                   "note": "full step at the default workload with emulated EOS positions: decode until the longest sequence ends, "
+                           "scoring and training on the packed rows (sum of lengths instead of G x C); one sample"}
 
     # ---- phase split + roofline of the dominant kernel, HIP events on the engine's stream (rank 0)
     if rank != 0:
@@ -538,6 +574,8 @@ def main():
         if recipe is not None:
             line["recipe_shape_samples_per_s"] = G * world / recipe        # 1 group per GPU per step, full step, one sample of it
             line["recipe_shape_ms_per_step"] = recipe * 1e3
+        if eos_mix is not None:
+            line["eos_mix"] = eos_mix
         line.update(extra)
         if roof:
             line["roofline"] = roof

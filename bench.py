@@ -370,8 +370,10 @@ def main():
         kind, lo, hi = a.eos_mix.split(":")
         assert kind == "uniform", "--eos-mix uniform:LO:HI"
         rng = np.random.default_rng(99 + rank)
-        lens_a = rng.integers(int(lo), min(int(hi), C) + 1, size=P * G)
-        lens_b = rng.integers(int(lo), min(int(hi), C) + 1, size=P * G)
+        hi = min(int(hi), C)
+        lo = max(1, min(int(lo), hi))                          # (short token budgets of rehearsal runs: clamp into [1, C])
+        lens_a = rng.integers(lo, hi + 1, size=P * G)
+        lens_b = rng.integers(lo, hi + 1, size=P * G)
         step(0, lens=lens_a)                                   # captures the decode graph of the shorter token budget
         barrier()
         t1 = time.perf_counter()
@@ -383,7 +385,7 @@ def main():
             te = torch.tensor([em], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             em = float(te.item())
-        eos_mix = {"lengths": f"uniform {lo}..{min(int(hi), C)} tokens per sequence (seeded), mean {float(lens_b.mean()):.0f}, longest {int(lens_b.max())}",
+        eos_mix = {"lengths": f"uniform {lo}..{hi} tokens per sequence (seeded), mean {float(lens_b.mean()):.0f}, longest {int(lens_b.max())}",
                    "samples_per_s": G * P * world / em, "ms_per_step": em * 1e3,
                    "note": "full step at the default workload with emulated EOS positions: decode until the longest sequence ends, "
                            "scoring and training on the packed rows (sum of lengths instead of G x C); one sample"}

@@ -270,11 +270,11 @@ def main():
 
     def step(i, rec=None, mine=None, lens=None):
         """One GRPO step over this rank's P prompt groups.  rec(name) marks a phase boundary (instrumented extra step only).
-        lens (host ints, one per sequence): emulated EOS positions -- see --eos-mix."""
+        lens (host ints, one per sequence): emulated EOS positions -- see --eos-mix (Engine.decode finish_at=)."""
         mark = rec if rec is not None else (lambda name: None)
         mine = prompts[i * P:(i + 1) * P] if mine is None else mine
         Pn = len(mine)
-        Cd = C if lens is None else min(C, -(-int(lens.max()) // 64) * 64)     # the decode checks for "all finished" every 64 steps
+
         # the step's P clips go through the vision tower in ONE pass and its P prompts through ONE policy prefill and ONE
         # reference prefill (M = P x 4096 patches / P x S tokens: every projection runs on full 256-row tiles)
         mark(None)
@@ -282,8 +282,9 @@ def main():
         mark("vit")
         states = eng.prefill_batch(pol, [(ids, enc[p_][0], enc[p_][1], [1.0]) for p_, (_, _, ids) in enumerate(mine)], slots[:Pn], tag="pol")
         mark("prefill")
-        toks_all, _ = eng.decode(pol, states, G, Cd, temperature=0.9, top_k=50, seed=1000 * rank + i, eos_token_id=None,
-                                 use_graph=not a.no_graph)
+        toks_all, _ = eng.decode(pol, states, G, C, temperature=0.9, top_k=50, seed=1000 * rank + i, eos_token_id=None,
+                                 use_graph=not a.no_graph, finish_at=lens)      # lens: the decode stops at its first 64-step check
+        Cd = int(toks_all.shape[1])                                             # past the longest sequence's (emulated) EOS
         mark("decode")
         eng.sync()
         comp_all = toks_all.cpu().numpy()                              # the rewards are host functions of the completions: ONE copy
@@ -374,7 +375,7 @@ def main():
         lo = max(1, min(int(lo), hi))                          # (short token budgets of rehearsal runs: clamp into [1, C])
         lens_a = rng.integers(lo, hi + 1, size=P * G)
         lens_b = rng.integers(lo, hi + 1, size=P * G)
-        step(0, lens=lens_a)                                   # captures the decode graph of the shorter token budget
+        step(0, lens=lens_a)                                   # captures the decode graph with the finished-sequence skip
         barrier()
         t1 = time.perf_counter()
         step(1, lens=lens_b)
@@ -387,8 +388,9 @@ def main():
             em = float(te.item())
         eos_mix = {"lengths": f"uniform {lo}..{hi} tokens per sequence (seeded), mean {float(lens_b.mean()):.0f}, longest {int(lens_b.max())}",
                    "samples_per_s": G * P * world / em, "ms_per_step": em * 1e3,
-                   "note": "full step at the default workload with emulated EOS positions: decode until the longest sequence ends, "
-                           "scoring and training on the packed rows (sum of lengths instead of G x C); one sample"}
+                   "note": "full step at the default workload with emulated EOS positions: decode until the longest sequence ends "
+                           "(finished sequences stop walking their own keys), scoring and training on the packed rows (sum of "
+                           "lengths instead of G x C); one sample"}
 
     # ---- phase split + roofline of the dominant kernel, HIP events on the engine's stream (rank 0)
     if rank != 0:

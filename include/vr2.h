@@ -149,14 +149,15 @@ int vr2_attn_tok(const void* work_i32x8, int64_t n_work, const void* Q_bf16, int
  * group g / seqs_per_group; group p's prefix KV starts at Kprefix + p*prefix_group_stride, length prefix_len_i32[p]
  * (<= prefix_chunk * n_prefix_chunks); the prefix chunks are computed once per GROUP for all its sequences, the suffix chunks
  * per sequence (step + 1 <= chunk * n_suffix_chunks); both chunk sizes are multiples of 64.  part_o: [G][n_heads][n_prefix_chunks + n_suffix_chunks][head_dim] f32,
- * part_ml: [..][2] f32. */
+ * part_ml: [..][2] f32.  finished_i32 (nullable, [G]): a sequence whose flag is set has produced its EOS -- every later token is
+ * the pad id whatever the model computes (generation/utils.py:2928-2929) -- and its own keys are not walked any more. */
 int vr2_attn_decode(const void* Q_bf16, int64_t ldq, const void* Kprefix, const void* Vprefix, const void* Ksuffix,
                     const void* Vsuffix, int64_t ldk, const void* prefix_len_i32, int64_t seqs_per_group,
                     int64_t prefix_group_stride, int64_t rows_per_seq, const void* step_i32,
                     int64_t chunk, int64_t prefix_chunk, int64_t n_prefix_chunks, int64_t n_suffix_chunks, int64_t G,
                     int64_t n_heads, int64_t group,
                     int64_t head_dim, float scale, void* part_o_f32, void* part_ml_f32, void* out_bf16, int64_t ldo,
-                    void* stream);
+                    const void* finished_i32, void* stream);
 
 /* ---- token level ------------------------------------------------------------------------------------------- */
 /* temperature / top-k / multinomial + EOS-pad bookkeeping (HF generation/logits_process.py:238,542;

@@ -26,7 +26,7 @@ for step in [int(a) for a in sys.argv[1:]] or [15, 255, 511, 1023]:
     def run():
         for l in range(L):
             lib.call("vr2_attn_decode", q, nH * hd, kp[l], vp[l], ks[l], vs[l], nKV * hd, plen, spg, S_ * nKV * hd, C, stp, schunk, pchunk,
-                     npc, nsc, G, nH, group, hd, hd ** -0.5, po, pml, out, nH * hd, st_)
+                     npc, nsc, G, nH, group, hd, hd ** -0.5, po, pml, out, nH * hd, None, st_)
     run(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

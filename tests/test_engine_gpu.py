@@ -492,6 +492,36 @@ def test_fp8_gemm_prefill_and_scoring_vs_quantised_oracle(golden_dir):
     assert np.abs(lp_q2 - lp_q).mean() < e_model                                # batched == single up to rounding-boundary flips
 
 
+def test_decode_stops_at_emulated_eos_and_live_sequences_are_untouched():
+    """Engine.decode(finish_at=): sequences flagged finished at a check point stop walking their own keys and the loop ends once all
+    are -- the sequences still running draw exactly the tokens of an unflagged run (same seed), which is what EOS-terminated rollouts
+    rely on (a finished neighbour must not perturb a live sequence)"""
+    ocfg = om.cfg_tiny(2)
+    eng, w, cfg = make_engine(ocfg, 33)
+    g = torch.Generator().manual_seed(6)
+    frames = torch.randint(0, 256, (4, 3, 56, 84), generator=g, dtype=torch.uint8).numpy()
+    px, grid = pixels_from_frames(frames, cfg.vision)
+    from video_r2_amd.host.processor import video_prompt_ids
+    prompt = np.asarray(video_prompt_ids(cfg, grid[0] * grid[1] * grid[2] // 4, [11, 12, 13], [21, 22, 23, 24]))
+    emb, plan = eng.encode_video(torch.from_numpy(px).to(eng.device), [grid])
+    st = eng.prefill(eng.text, prompt, emb, plan, [1.0])
+    G, C = 4, 24
+    full, _ = eng.decode(eng.text, st, G, C, seed=9, use_graph=True)
+    full = full.cpu().clone()
+    fin = np.asarray([5, 24, 9, 14])
+    part, _ = eng.decode(eng.text, st, G, C, seed=9, use_graph=True, check_every=4, finish_at=fin)
+    part = part.cpu()
+    assert part.shape[1] == C                                   # sequence 1 runs to the end
+    for gq in range(G):
+        # flagged at the first check at or after its length: up to there nothing differs; the live ones never differ
+        seen = -(-max(int(fin[gq]) - 1, 1) // 4) * 4 + 1
+        upto = C if fin[gq] >= C else min(C, seen)
+        assert torch.equal(part[gq, :upto], full[gq, :upto]), gq
+    assert torch.equal(part[1], full[1])
+    short, _ = eng.decode(eng.text, st, G, C, seed=9, use_graph=True, check_every=4, finish_at=[3, 6, 2, 5])
+    assert short.shape[1] == 9                                  # 1 + 8 decode steps: the check after step 8 sees >= 6 tokens everywhere
+
+
 def test_text_only_prompt_logps_vs_oracle():
     """a prompt without any video (the reference's dataset also carries text-only rows): no vision tower, 1-D rope positions;
     scoring and the decode path against the fp32 oracle"""

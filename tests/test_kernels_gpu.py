@@ -342,12 +342,43 @@ def test_attn_decode(dev, group, step):
     plen = torch.tensor([Sp], dtype=torch.int32, device=dev)
     lib.call("vr2_attn_decode", q.view(G, -1).to(dev), nH * hd, kp.view(Sp, -1).to(dev), vp_.view(Sp, -1).to(dev),
              ks.view(G * C, -1).to(dev), vs.view(G * C, -1).to(dev), nKV * hd, plen, G, 0, C, st, chunk, chunk, npc, nsc, G, nH, group, hd,
-             hd ** -0.5, po, pml, out, nH * hd, S())
+             hd ** -0.5, po, pml, out, nH * hd, None, S())
     out = out.float().cpu().view(G, nH, hd)
     for gg in range(G):
         for h in range(nH):
             kk = torch.cat([kp[:, h // group], ks[gg * C:gg * C + step + 1, h // group]]).float()
             vv = torch.cat([vp_[:, h // group], vs[gg * C:gg * C + step + 1, h // group]]).float()
+            ref = _attn_ref(q[gg, h:h + 1].float(), kk, vv, hd ** -0.5, torch.ones(1, kk.shape[0], dtype=torch.bool))
+            assert (out[gg, h] - ref[0]).abs().max().item() < 2 ** -6 * max(1.0, ref.abs().max().item())
+
+
+def test_attn_decode_skips_the_own_keys_of_finished_sequences(dev):
+    """finished_i32: a sequence that has produced its EOS no longer walks its own suffix keys (its later tokens are pad ids whatever
+    the model computes): its output is the attention over the shared prefix alone, the live sequences are untouched -- also when the
+    partial slots still hold an earlier step's values"""
+    hd, nKV, group, G, Sp, C, step = 128, 2, 7, 3, 200, 256, 130
+    nH = nKV * group
+    g = torch.Generator().manual_seed(5)
+    kp = bf(torch.randn(Sp, nKV, hd, generator=g)); vp_ = bf(torch.randn(Sp, nKV, hd, generator=g))
+    ks = bf(torch.randn(G * C, nKV, hd, generator=g)); vs = bf(torch.randn(G * C, nKV, hd, generator=g))
+    q = bf(torch.randn(G, nH, hd, generator=g))
+    chunk = 64
+    npc, nsc = (Sp + chunk - 1) // chunk, (C + chunk - 1) // chunk
+    nch = npc + nsc
+    po = torch.full((G * nH * nch, hd), 3.0, device=dev); pml = torch.full((G * nH * nch, 2), 1.0, device=dev)   # stale slots
+    out = torch.zeros(G, nH * hd, dtype=torch.bfloat16, device=dev)
+    st = torch.tensor([step], dtype=torch.int32, device=dev)
+    plen = torch.tensor([Sp], dtype=torch.int32, device=dev)
+    fin = torch.tensor([0, 1, 0], dtype=torch.int32, device=dev)
+    lib.call("vr2_attn_decode", q.view(G, -1).to(dev), nH * hd, kp.view(Sp, -1).to(dev), vp_.view(Sp, -1).to(dev),
+             ks.view(G * C, -1).to(dev), vs.view(G * C, -1).to(dev), nKV * hd, plen, G, 0, C, st, chunk, chunk, npc, nsc, G, nH, group, hd,
+             hd ** -0.5, po, pml, out, nH * hd, fin, S())
+    out = out.float().cpu().view(G, nH, hd)
+    for gg in range(G):
+        own = 0 if gg == 1 else step + 1
+        for h in range(nH):
+            kk = torch.cat([kp[:, h // group], ks[gg * C:gg * C + own, h // group]]).float()
+            vv = torch.cat([vp_[:, h // group], vs[gg * C:gg * C + own, h // group]]).float()
             ref = _attn_ref(q[gg, h:h + 1].float(), kk, vv, hd ** -0.5, torch.ones(1, kk.shape[0], dtype=torch.bool))
             assert (out[gg, h] - ref[0]).abs().max().item() < 2 ** -6 * max(1.0, ref.abs().max().item())
 
@@ -373,7 +404,7 @@ def test_attn_decode_two_prompt_groups(dev):
     plen = torch.tensor(lens, dtype=torch.int32, device=dev)
     lib.call("vr2_attn_decode", q.view(G, -1).to(dev), nH * hd, kp.view(P * Smax, -1).to(dev), vp_.view(P * Smax, -1).to(dev),
              ks.view(G * C, -1).to(dev), vs.view(G * C, -1).to(dev), nKV * hd, plen, spg, Smax * nKV * hd, C, st, chunk, pchunk, npc, nsc, G, nH,
-             group, hd, hd ** -0.5, po, pml, out, nH * hd, S())
+             group, hd, hd ** -0.5, po, pml, out, nH * hd, None, S())
     out = out.float().cpu().view(G, nH, hd)
     for gg in range(G):
         p = gg // spg

@@ -274,7 +274,7 @@ __device__ __forceinline__ void decode_suffix_body(bf16* sK, bf16* sV, int c, in
                                                    const bf16* __restrict__ KS, const bf16* __restrict__ VS, long ldk,
                                                    long rows_per_seq, const int* __restrict__ step, int chunk, int npc, int nslot,
                                                    int group, int n_heads, float scale, float* __restrict__ po,
-                                                   float* __restrict__ pml) {
+                                                   float* __restrict__ pml, const int* __restrict__ finished) {
   constexpr int KTS = VR2_KTS;   // 16-key LDS tiles (9 KiB per wave), loaded one tile ahead: 44.2 / 38.7 / 36.8 us per layer for
                                  // 64- / 32- / 16-key tiles at 128 sequences, C = 1024, 256-key chunks
   constexpr int NKS = HD / 16;
@@ -286,6 +286,15 @@ __device__ __forceinline__ void decode_suffix_body(bf16* sK, bf16* sV, int c, in
   const int fr = lane & 15, fq = lane >> 4;
   const bool qvalid = fr < group;
   const int head = kvh * group + (qvalid ? fr : 0);
+  if (finished && finished[g]) {
+    // the sequence has produced its EOS: every later token is the pad id whatever the model computes (generation/utils.py:2928-2929),
+    // so its own keys are not walked any more; the chunk's slot says "empty" (weight 0 in the combine, stale values never read)
+    if (qvalid && fq == 0) {
+      const long pslot = ((long)g * n_heads + head) * nslot + npc + c;
+      pml[pslot * 2] = -INFINITY; pml[pslot * 2 + 1] = 0.f;
+    }
+    return;
+  }
   s16x4 qf[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks)
@@ -318,7 +327,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict
                                                           int seqs_per_group, long prefix_group_stride, long rows_per_seq,
                                                           const int* __restrict__ step, int schunk, int pchunk, int npc, int nsc,
                                                           int n_suffix_blocks, int n_kv, int G, int slot_blocks, int group,
-                                                          int n_heads, float scale, float* __restrict__ po, float* __restrict__ pml) {
+                                                          int n_heads, float scale, float* __restrict__ po, float* __restrict__ pml,
+                                                          const int* __restrict__ finished) {
   constexpr int KTP = VR2_KTP, KTS = VR2_KTS;
   static_assert(KTP >= 4 * KTS, "four suffix waves share the prefix tile's LDS");
   __shared__ __attribute__((aligned(16))) bf16 sK[KTP * Strides<HD>::K];
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict
     if (item >= nsc * n_kv * G) return;
     const int c = item % nsc, kvh = (item / nsc) % n_kv, g = item / (nsc * n_kv);
     decode_suffix_body<HD>(sK + wave * KTS * Strides<HD>::K, sV + wave * KTS * Strides<HD>::V, c, kvh, g, Q, ldq, KS, VS, ldk, rows_per_seq,
-                           step, schunk, npc, nslot, group, n_heads, scale, po, pml);
+                           step, schunk, npc, nslot, group, n_heads, scale, po, pml, finished);
   } else {
     const int b = (int)blockIdx.x - n_suffix_blocks;
     const int c = b % npc, kvh = (b / npc) % n_kv, bz = b / (npc * n_kv);
@@ -432,7 +442,7 @@ extern "C" int vr2_attn_decode(const void* Q, int64_t ldq, const void* Kprefix, 
                                const void* step_i32, int64_t chunk, int64_t prefix_chunk, int64_t n_prefix_chunks,
                                int64_t n_suffix_chunks, int64_t G,
                                int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* part_o_f32,
-                               void* part_ml_f32, void* out_bf16, int64_t ldo, void* stream) {
+                               void* part_ml_f32, void* out_bf16, int64_t ldo, const void* finished_i32, void* stream) {
   VR2_REQUIRE(head_dim == 128, "vr2_attn_decode: head_dim %ld not built (128 is)", (long)head_dim);
   VR2_REQUIRE(group >= 1 && group <= 16 && n_heads % group == 0, "vr2_attn_decode: GQA group %ld must be in [1,16]", (long)group);
   VR2_REQUIRE(chunk % 64 == 0 && prefix_chunk % 64 == 0 && prefix_chunk >= 64 && n_prefix_chunks >= 1 && n_suffix_chunks >= 1 &&
@@ -450,7 +460,7 @@ extern "C" int vr2_attn_decode(const void* Q, int64_t ldq, const void* Kprefix, 
                      (const bf16*)Kprefix, (const bf16*)Vprefix, (const bf16*)Ksuffix, (const bf16*)Vsuffix, (long)ldk,
                      (const int*)prefix_len_i32, (int)seqs_per_group, (long)prefix_group_stride, (long)rows_per_seq, (const int*)step_i32,
                      (int)chunk, (int)prefix_chunk, npc, (int)n_suffix_chunks, n_suffix_blocks, (int)n_kv, (int)G, slot_blocks, (int)group,
-                     (int)n_heads, scale, (float*)part_o_f32, (float*)part_ml_f32);
+                     (int)n_heads, scale, (float*)part_o_f32, (float*)part_ml_f32, (const int*)finished_i32);
   if (vr2_check_launch("vr2_attn_decode(prefix + suffix)")) return -1;
   hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)n_heads, (unsigned)G), dim3(64), 0, s, (const float*)part_o_f32,
                      (const float*)part_ml_f32, npc, nslot, (int)head_dim, (bf16*)out_bf16, (long)ldo, (int)n_heads,

@@ -604,7 +604,7 @@ class Engine:
                      bufs["step"], self.inv_freq, G, nq, nkv, hd, q, q.stride(0), sk, sv, sk.stride(0), C, self.s)
             lib.call("vr2_attn_decode", q, q.stride(0), bufs["pk"][l], bufs["pv"][l], sk, sv, sk.stride(0), bufs["plen"],
                      bufs["spg"], bufs["pstride"], C, bufs["step"], bufs["schunk"], bufs["pchunk"], bufs["npc"], bufs["nsc"], G, nq, t.group, hd, scale,
-                     bufs["part_o"], bufs["part_ml"], att, att.stride(0), self.s)
+                     bufs["part_o"], bufs["part_ml"], att, att.stride(0), bufs.get("skip_finished"), self.s)
             self._gemv(att, W, f"l{l}.o_w", G, p_o, ns_o)
             self._norm(x, W[f"l{l}.ln2"], xn, G, H, t.rms_norm_eps, partial=p_o, nsplit=ns_o, q8=fq)
             f8 = self._f8(W, f"l{l}.gu_w", G)
@@ -696,12 +696,15 @@ class Engine:
 
     @_on_stream
     def decode(self, W: Params, st, G, max_new_tokens, temperature=0.9, top_k=50, seed=0, eos_token_id=None,
-               use_graph=True, forced_tokens=None, check_every=64, top_p=1.0, min_p=None, repetition_penalty=1.0):
+               use_graph=True, forced_tokens=None, check_every=64, top_p=1.0, min_p=None, repetition_penalty=1.0, finish_at=None):
         """Sample G completions per prompt group of up to max_new_tokens.  ``st``: one PromptState, or a list of P states whose
         prefix KV live in ``prefix_slots`` (P prompt groups decoded together: P*G <= 128 rows per weight pass, so the weights
         are streamed once for all of them).  -> (int32 [P*G, C'] device, buffers).
         eos_token_id=None disables EOS (fixed length).  forced_tokens [P*G,C] (host ints) teacher-forces the inputs
         (the sampled tokens are still produced, from the same logits, for comparison).
+        finish_at (host ints [P*G], benchmarks only): EOS positions EMULATED for models that never emit one (random-init
+        weights): at every check point the sequences that have produced finish_at[g] tokens are flagged finished, exactly as if
+        they had sampled their EOS there -- the decode stops once all are, finished sequences stop walking their own keys.
         top_p / min_p / repetition_penalty: HF generate's warpers and processor (grpo_trainer.py:559-570 forwards them); top_p < 1
         and min_p > 0 need 1 <= top_k <= 64; the penalty covers prompt + generated ids (PromptState.input_ids).
 
@@ -733,6 +736,10 @@ class Engine:
                 if s_.prefix_k.data_ptr() != k0.data_ptr() + p_ * pstride * k0.element_size() or s_.prefix_k.stride() != k0.stride():
                     raise ValueError("multi-group decode needs prefix caches from Engine.prefix_slots (uniform group stride)")
         b["pk"], b["pv"], b["spg"], b["pstride"] = k0, v0, G, pstride
+        # finished sequences (EOS sampled: pad tokens from then on) stop walking their own keys; not when the inputs are forced --
+        # a teacher-forced row goes on whatever the sampler drew -- and not with EOS off
+        b["skip_finished"] = b["finished"] if (forced_tokens is None and (eos >= 0 or finish_at is not None)) else None
+        d_finish = None if finish_at is None else torch.as_tensor(np.asarray(finish_at), dtype=torch.int32).to(self.device)
         b["plen"] = self.buf("d.plen%d" % P, (P,), torch.int32)
         pos0 = torch.tensor([s_.n_prompt + s_.rope_delta for s_ in states for _ in range(G)], dtype=torch.int32)
         plen = torch.tensor([s_.n_prompt for s_ in states], dtype=torch.int32)
@@ -763,7 +770,7 @@ class Engine:
             seen0 = torch.from_numpy(np.packbits(bits, axis=1, bitorder="little").view(np.int32).copy())
         step_args = (W, None, NG, C, b, temperature, top_k, seed_dev, eos, cfg.pad_token_id, top_p, min_p, rep)
         key = (id(W), NG, P, C, cap_s, float(temperature), int(top_k), eos, k0.data_ptr(), pstride, self._ws_epoch, bool(self.decode_fp8),
-               bool(self.decode_fp8_act), top_p, min_p, rep)
+               bool(self.decode_fp8_act), top_p, min_p, rep, b["skip_finished"] is not None)
         graph = None
         if getattr(self, "_graph_epoch", -1) != self._ws_epoch:       # a workspace moved: every captured graph is stale
             for ex_ in self._graphs.values():
@@ -805,7 +812,9 @@ class Engine:
             else:
                 self._decode_step(*step_args)
             steps_done = step + 1
-            if eos >= 0 and forced is None and (step + 1) % check_every == 0:
+            if (eos >= 0 or d_finish is not None) and forced is None and (step + 1) % check_every == 0:
+                if d_finish is not None:
+                    b["finished"].copy_((d_finish <= step + 2).to(torch.int32))      # step + 2 tokens exist per sequence by now
                 self.sync()
                 if bool(b["finished"].all().item()):
                     break

@@ -213,6 +213,7 @@ def launch_check(a, world, rank, backend):
 
 
 def main():
+    t_start = time.perf_counter()
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
@@ -331,12 +332,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def say(msg):        # progress on stderr (rank 0): a run of several minutes must not look hung to whoever launched it
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    say(f"weights, optimiser state and {n_prompts} synthetic prompts resident; {a.warmup} warm-up + {a.steps} timed steps of {P} groups")
     for i in range(a.warmup):
         step(i)
+        say(f"warm-up step {i + 1}/{a.warmup} done")
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
+        if (i + 1) % 4 == 0 or i + 1 == a.steps:
+            say(f"timed step {i + 1}/{a.steps} done ({(time.perf_counter() - t0) / (i + 1):.2f} s per step so far)")
     barrier()
     dt = time.perf_counter() - t0
     rank_dt = [dt]
@@ -351,6 +360,7 @@ def main():
     # ---- the reference recipe's per-device shape: ONE prompt group per GPU per optimiser step (train_grpo.sh:4-7:
     # per_device_train_batch_size 1 -> G rows per decode weight pass).  Untimed for `value`; reported beside it.
     recipe = None
+    say("timed region done; untimed extras follow (recipe shape, emulated EOS mix, instrumented step, roofline kernels)")
     if not a.no_recipe_shape and P > 1:
         step(0, mine=prompts[-2:-1])                           # captures the G-row decode graph
         barrier()
@@ -376,6 +386,7 @@ def main():
         lens_a = rng.integers(lo, hi + 1, size=P * G)
         lens_b = rng.integers(lo, hi + 1, size=P * G)
         step(0, lens=lens_a)                                   # captures the decode graph with the finished-sequence skip
+        say("eos-mix warm-up step done")
         barrier()
         t1 = time.perf_counter()
         step(1, lens=lens_b)
@@ -393,6 +404,7 @@ def main():
                            "lengths instead of G x C); one sample"}
 
     # ---- phase split + roofline of the dominant kernel, HIP events on the engine's stream (rank 0)
+    say("extras done; instrumented step")
     if rank != 0:
         step(a.warmup + a.steps)      # the instrumented step below runs on EVERY rank: its optimiser step is a collective
     extra = {}
@@ -584,6 +596,7 @@ def main():
         if roof:
             line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
+            say("CPU baseline (bounded sample of the oracle)")
             line["cpu_baseline"] = cpu_baseline(a.model, a.frames, G, C)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -344,3 +344,26 @@ def test_key_work_covers_every_visible_pair_once():
             steps.append(nh * (-(-l1 // 64) + -(-l2 // 64)))
         assert (seen == allow[None].astype(np.int32)).all()
         assert steps == sorted(steps, reverse=True)
+
+
+def test_phase_timer_reports_host_phases_under_the_reference_metric_names():
+    """video_r2_amd.profiling.PhaseTimer without a GPU: host phases are wall-clock intervals, summed per name; names every rank must
+    report appear with 0.0 when nothing ran under them; collect() resets"""
+    import time
+    from video_r2_amd.profiling import PhaseTimer
+    t = PhaseTimer("QwenGRPOTrainer", stream=None)
+    with t.host("format_reward"):
+        time.sleep(0.01)
+    with t.host("format_reward"):
+        time.sleep(0.01)
+    with t.phase("generate"):          # no stream: falls back to the wall clock
+        time.sleep(0.005)
+    got = t.collect(expect=["backward"])
+    assert set(got) == {"profiling/Time taken: QwenGRPOTrainer.format_reward", "profiling/Time taken: QwenGRPOTrainer.generate",
+                        "profiling/Time taken: QwenGRPOTrainer.backward"}
+    assert got["profiling/Time taken: QwenGRPOTrainer.format_reward"] >= 0.02 and got["profiling/Time taken: QwenGRPOTrainer.backward"] == 0.0
+    assert t.collect() == {}
+    off = PhaseTimer(enabled=False)
+    with off.phase("x"), off.host("y"):
+        pass
+    assert off.collect() == {}

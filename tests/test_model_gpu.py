@@ -208,6 +208,11 @@ def test_trainer_step_metrics_and_loss():
     for k in ("completions/mean_length", "completions/clipped_ratio", "reward", "reward_std", "rewards/format_reward/mean",
               "rewards/accuracy_reward/mean", "clip_ratio/low_mean", "clip_ratio/high_max", "clip_ratio/region_mean", "num_tokens"):
         assert k in out["metrics"], k
+    # phase times under the reference's metric names (profiling_decorator / profiling_context, grpo_trainer.py:711-722,850): HIP events
+    # on the engine stream for the device phases, wall clock for the reward functions
+    pt = {k.split(".")[-1]: v for k, v in out["metrics"].items() if k.startswith("profiling/Time taken: QwenGRPOTrainer.")}
+    assert set(pt) == {"generate", "_get_per_token_logps", "backward", "optimizer_step", "format_reward", "accuracy_reward"}, pt
+    assert all(v >= 0 for v in pt.values()) and pt["generate"] > 0 and pt["_get_per_token_logps"] > 0 and pt["backward"] > 0
 
 
 def _dp_worker(rank, world, port, q, backend="gloo"):

@@ -99,6 +99,7 @@ class GRPOArguments:
                                       # on the fp8 MFMA (BASELINE config 5); "fp8w": weight-only fp8
     pack_completions: bool = True    # score / train on each completion up to its first EOS only (rows behind it are masked out of the
                                       # loss anyway): sum of lengths rows per group instead of G x max length
+    profile_phases: bool = True      # profiling/Time taken: QwenGRPOTrainer.<phase> metrics (HIP events on the engine stream) + roctx ranges
     async_rewards: bool = True        # reward functions run on a background thread behind the reference-model scoring
     reward_workers: int = 4           # each reward function scores this many slices of the step's completions concurrently (1 = one call)
     ignored: dict = field(default_factory=dict)

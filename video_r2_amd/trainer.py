@@ -24,7 +24,8 @@ from .train import Trainer as UpdateEngine
 from .train import cosine_lr
 
 
-def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_example, args, sentence_model=None, pool=None, workers=1):
+def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_example, args, sentence_model=None, pool=None, workers=1,
+                      timer=None):
     """The reward loop of the reference (grpo_trainer.py:846-892) for whole prompt groups: one row per completion, in group
     order.  Every dataset column except "prompt" / "completion" is repeated per completion and forwarded, plus the three knobs
     of :871-875; the TAR family additionally gets sentence_model= (:878-886).  None -> NaN.  -> fp32 [rows, n_funcs] (CPU).
@@ -53,11 +54,13 @@ def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_examp
         def part(a, b, fn=fn, extra=extra):
             sl = {k: (v[a:b] if k in per_row else v) for k, v in kw.items()}
             return fn(prompts=prompts[a:b], completions=completions[a:b], **extra, **sl)
-        if len(cuts) == 2:
-            vals = part(0, n)
-        else:
-            futs = [pool.submit(part, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
-            vals = [v for f in futs for v in f.result()]
+        import contextlib
+        with (timer.host(name) if timer is not None else contextlib.nullcontext()):   # profiling_context(self, reward_func_name), :850
+            if len(cuts) == 2:
+                vals = part(0, n)
+            else:
+                futs = [pool.submit(part, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+                vals = [v for f in futs for v in f.result()]
         out[:, i] = torch.tensor([float("nan") if v is None else float(v) for v in vals], dtype=torch.float32)
     if len(prompts) and torch.isnan(out).all(dim=1).any():
         row = int(torch.isnan(out).all(dim=1).nonzero()[0, 0])
@@ -137,6 +140,8 @@ class QwenGRPOTrainer:
                 if self.ref_params is not None:  # fp8 operands too (vr2_gemm_a8w8); the reference model is frozen: quantised once
                     vw.add_fp8_decode_copies(self.ref_params)
                 model.engine.gemm_fp8 = True
+        from .profiling import PhaseTimer
+        self.prof = PhaseTimer("QwenGRPOTrainer", stream=model.engine.stream, enabled=getattr(args, "profile_phases", True))
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
         self._row_pool = None                        # --reward_workers threads that split a reward function's rows
         self.update = not getattr(args, "freeze_llm", False)
@@ -186,12 +191,13 @@ class QwenGRPOTrainer:
             # the chunk's clips go through the vision tower in ONE pass and its prompts through ONE prefill (full GEMM tiles)
             slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="pol")
             clips = [self._clips(pi) for pi in pis]
-            enc = eng.encode_videos([c for cl in clips for c in cl], per_prompt=[len(cl) for cl in clips])
-            encs = [(emb, plan, pi.get("second_per_grid_ts")) for (emb, plan), pi in zip(enc, pis)]
-            states = eng.prefill_batch(m.text, [(ids, emb, plan, sec) for ids, (emb, plan, sec) in zip(idss, encs)], slots, tag="pol")
-            toks_all, _ = eng.decode(m.text, states if len(states) > 1 else states[0], G, a.max_completion_length,
-                                     temperature=a.temperature, top_k=a.top_k, seed=seed + 7919 * c0,
-                                     eos_token_id=m.cfg.eos_token_id, **self.sampling)
+            with self.prof.phase("generate"):          # vision tower + prompt prefill + decode (model.generate, :783-786)
+                enc = eng.encode_videos([c for cl in clips for c in cl], per_prompt=[len(cl) for cl in clips])
+                encs = [(emb, plan, pi.get("second_per_grid_ts")) for (emb, plan), pi in zip(enc, pis)]
+                states = eng.prefill_batch(m.text, [(ids, emb, plan, sec) for ids, (emb, plan, sec) in zip(idss, encs)], slots, tag="pol")
+                toks_all, _ = eng.decode(m.text, states if len(states) > 1 else states[0], G, a.max_completion_length,
+                                         temperature=a.temperature, top_k=a.top_k, seed=seed + 7919 * c0,
+                                         eos_token_id=m.cfg.eos_token_id, **self.sampling)
             new = []
             for p_, (pi, ids) in enumerate(zip(pis, idss)):
                 toks = toks_all[p_ * G:(p_ + 1) * G]
@@ -211,19 +217,20 @@ class QwenGRPOTrainer:
                         from concurrent.futures import ThreadPoolExecutor
                         self._reward_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="vr2-rewards")
                     pending = self._reward_pool.submit(self._rewards, examples, groups)
-            if self.beta != 0.0:     # the reference model's prompt prefill, batched the same way
-                ref_slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="ref")
-                ref_states = eng.prefill_batch(self.ref_params, [(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"]) for ro in new], ref_slots, tag="ref")
-            for k_, ro in enumerate(new):   # scoring while the chunk's prefix caches are still in place
-                if self.beta != 0.0:
-                    ro["ref_logps"] = eng.score(self.ref_params, ref_states[k_], ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"])
-                    if len(examples) > 1:
-                        ro["ref_logps"] = ro["ref_logps"].clone()  # the scoring output is a reused workspace
-                if not self.update:
-                    ro["logps"] = eng.score(m.text, ro["_state"], ro["completion_ids"], a.temperature, tag="pol", lens=ro["lens"])
-                    if len(examples) > 1:
-                        ro["logps"] = ro["logps"].clone()
-                ro.pop("_state")
+            with self.prof.phase("_get_per_token_logps"):     # (the reference decorates this method: :722)
+                if self.beta != 0.0:     # the reference model's prompt prefill, batched the same way
+                    ref_slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="ref")
+                    ref_states = eng.prefill_batch(self.ref_params, [(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"]) for ro in new], ref_slots, tag="ref")
+                for k_, ro in enumerate(new):   # scoring while the chunk's prefix caches are still in place
+                    if self.beta != 0.0:
+                        ro["ref_logps"] = eng.score(self.ref_params, ref_states[k_], ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"])
+                        if len(examples) > 1:
+                            ro["ref_logps"] = ro["ref_logps"].clone()  # the scoring output is a reused workspace
+                    if not self.update:
+                        ro["logps"] = eng.score(m.text, ro["_state"], ro["completion_ids"], a.temperature, tag="pol", lens=ro["lens"])
+                        if len(examples) > 1:
+                            ro["logps"] = ro["logps"].clone()
+                    ro.pop("_state")
         rewards = pending.result() if pending is not None else self._rewards(examples, groups)
         return groups, rewards
 
@@ -237,7 +244,7 @@ class QwenGRPOTrainer:
             from concurrent.futures import ThreadPoolExecutor
             self._row_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vr2-reward-rows")
         return call_reward_funcs(self.reward_funcs, self.reward_func_names, examples, texts, self.args, self.sentence_model,
-                                 pool=self._row_pool, workers=workers)
+                                 pool=self._row_pool, workers=workers, timer=self.prof)
 
     # ------------------------------------------------------------------ one optimisation step (forward half)
     def step(self, step_examples, processed=None):
@@ -277,8 +284,9 @@ class QwenGRPOTrainer:
         for i, ro in enumerate(rollouts):
             live = ro["lens"] is None or int(ro["lens"].sum()) > 0       # (a group whose completions are all masked out has no rows)
             if self.update and live:      # policy log-probs WITH saved activations (the forward of grpo_trainer.py:1094-1096)
-                ro["logps"] = self.updater.forward(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"], a.temperature,
-                                                   lens=ro["lens"])
+                with self.prof.phase("_get_per_token_logps"):
+                    ro["logps"] = self.updater.forward(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"], a.temperature,
+                                                       lens=ro["lens"])
             elif self.update:
                 ro["logps"] = torch.zeros(ro["completion_ids"].shape, dtype=torch.float32, device=dev)
             with torch.cuda.stream(eng.stream):
@@ -289,7 +297,8 @@ class QwenGRPOTrainer:
                 if scale[i] != 1.0:
                     out["dlogp"].mul_(scale[i]); out["loss"] = out["loss"] * scale[i]
             if self.update and live:
-                self.updater.backward(out["dlogp"], exchange=(i == len(rollouts) - 1))   # gradients accumulate over the groups
+                with self.prof.phase("backward"):
+                    self.updater.backward(out["dlogp"], exchange=(i == len(rollouts) - 1))   # gradients accumulate over the groups
             ro["dlogp"] = out["dlogp"]
             outs.append(out)
         eng.sync()                                                   # ONE host sync for the step's groups: the scalars are read
@@ -326,13 +335,19 @@ class QwenGRPOTrainer:
             kinds.update({f"_r{j}/n": "sum", f"_r{j}/s": "sum", f"_r{j}/ss": "sum"})
         if self.update:
             lr = cosine_lr(a.learning_rate, self.global_step, self.total_steps, int(a.warmup_ratio * self.total_steps))
-            gn = self.updater.optimizer_step(lr=lr, weight_decay=a.weight_decay, beta1=a.adam_beta1, beta2=a.adam_beta2,
-                                             eps=a.adam_epsilon, max_grad_norm=a.max_grad_norm, grad_scale=1.0 / len(rollouts))
+            with self.prof.phase("optimizer_step"):
+                gn = self.updater.optimizer_step(lr=lr, weight_decay=a.weight_decay, beta1=a.adam_beta1, beta2=a.adam_beta2,
+                                                 eps=a.adam_epsilon, max_grad_norm=a.max_grad_norm, grad_scale=1.0 / len(rollouts))
             local["grad_norm"] = gn.item()
+            eng.sync()
             local["learning_rate"] = lr
             if self.model.engine.decode_fp8:                      # the next rollout decodes the updated policy
                 with torch.cuda.stream(self.model.engine.stream):
                     vw.add_fp8_decode_copies(self.model.text)
+        eng.sync()
+        if self.prof.enabled:                 # profiling/Time taken: QwenGRPOTrainer.<phase or reward function>: seconds, mean over ranks
+            local.update(self.prof.collect(["generate", "_get_per_token_logps"] + (["backward", "optimizer_step"] if self.update else [])
+                                           + list(self.reward_func_names)))
         red = self.reducer.reduce(local, kinds)
         for j, name in enumerate(self.reward_func_names):
             n_, s_, ss_ = red.pop(f"_r{j}/n"), red.pop(f"_r{j}/s"), red.pop(f"_r{j}/ss")

@@ -85,3 +85,12 @@ def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
     # the resumed step 3 sees the same prompts and the same sampling seed as the first run's step 3, from the same weights
     assert steps2[0]["completions/mean_length"] == steps[2]["completions/mean_length"]
     assert steps2[0]["loss"] == pytest.approx(steps[2]["loss"], rel=1e-5, abs=1e-7)
+    # third launch into a fresh output directory: BASELINE config 5 (fp8 decode + fp8 no-grad GEMMs) with HF's top-p / min-p /
+    # repetition-penalty flags and the phase timers, through the same shell entry -- the flags must reach the engine, not be dropped
+    env3 = dict(env, OUTPUT_DIR=str(tmp_path / "out_fp8"))
+    steps3, err3 = _launch(env3, *flags, "--max_steps", "2", "--decode_weights", "fp8", "--top_p", "0.9", "--min_p", "0.02",
+                           "--repetition_penalty", "1.1", "--top_k", "40")
+    assert [s["step"] for s in steps3] == [1, 2], err3[-3000:]
+    for s in steps3:
+        assert np.isfinite(s["loss"]) and s["grad_norm"] > 0
+        assert s["profiling/Time taken: QwenGRPOTrainer.generate"] > 0 and "profiling/Time taken: QwenGRPOTrainer.text_length_reward" in s

@@ -544,14 +544,20 @@ def main():
                                            "avg_launch_us": g_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H}
         # the weight-gradient GEMM of the same layer (dW[2I][H] += dY[T][2I]^T X[T][H]): the largest launch of the backward
         if hasattr(upd, "state") and "l0.gu_w" in getattr(upd.state, "grad", {}):
-            dya = torch.randn(Tr, n_gu, device=device).to(torch.bfloat16)
+            # operands = the step's own buffers (dY: the gate/up pre-activation gradients the last backward left in its workspace,
+            # X: the saved normed inputs of layer 0): allocated at start-up like every launch of the step.  Operands allocated
+            # HERE, with 250 GB already in use, ran the same launch 20 % slower (2.72 vs 2.25 ms) -- late allocations come from
+            # fragmented physical memory -- while the step's own launches average the isolated time under rocprofv3
+            I16 = (I + 15) // 16 * 16
+            dya = eng.buf("t.dgu", (Tr, 2 * I16), torch.bfloat16) if 2 * I16 == n_gu else torch.randn(Tr, n_gu, device=device).to(torch.bfloat16)
+            xw = eng.buf("t.xn2", (Lh, Tr, H), torch.bfloat16)[0]
             gw_ = upd.state.grad["l0.gu_w"]
             keep = gw_.clone()
             wreps = 3
-            lib.call("vr2_gemm_tn_bf16", dya, n_gu, xa, H, gw_, gw_.stride(0), n_gu, H, Tr, 1, eng.s)
+            lib.call("vr2_gemm_tn_bf16", dya, dya.stride(0), xw, xw.stride(0), gw_, gw_.stride(0), n_gu, H, Tr, 1, eng.s)
             L.vr2_event_record(e0, ctypes.c_void_p(eng.s))
             for _ in range(wreps):
-                lib.call("vr2_gemm_tn_bf16", dya, n_gu, xa, H, gw_, gw_.stride(0), n_gu, H, Tr, 1, eng.s)
+                lib.call("vr2_gemm_tn_bf16", dya, dya.stride(0), xw, xw.stride(0), gw_, gw_.stride(0), n_gu, H, Tr, 1, eng.s)
             L.vr2_event_record(e1, ctypes.c_void_p(eng.s))
             eng.sync()
             w_ms = elapsed(e0, e1) / wreps
@@ -560,7 +566,7 @@ def main():
             extra["roofline_wgrad"] = {"bound": "mfma", "kernel": "gemm_tn256_kernel<1> (+ <2>: last round as k-parts) (gate/up weight gradient, %d x %d x %d, fp32 +=)" % (n_gu, H, Tr),
                                        "achieved": w_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": w_tf / 2500.0, "traffic": None,
                                        "avg_launch_us": w_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H}
-            del dya, keep
+            del keep
         del xa, ya
 
     if rank == 0:

@@ -215,6 +215,43 @@ def test_trainer_step_metrics_and_loss():
     assert all(v >= 0 for v in pt.values()) and pt["generate"] > 0 and pt["_get_per_token_logps"] > 0 and pt["backward"] > 0
 
 
+def test_sync_ref_model_mixes_the_policy_into_the_reference():
+    """--sync_ref_model (TRL's SyncRefModelCallback behind grpo_trainer.py:587-588): after every ref_model_sync_steps optimiser
+    steps ref <- alpha * policy + (1 - alpha) * ref, on every LM tensor; off by default (the reference stays the SFT model)"""
+    from video_r2_amd import params, rewards
+    from video_r2_amd.trainer import QwenGRPOTrainer
+    m, w, ocfg = _model(2, 37)
+    cfg = m.cfg
+    args = params.parse_args(["--num_generations", "4", "--max_completion_length", "8", "--beta", "0.04", "--learning_rate", "1e-2",
+                              "--reward_func_names", "format_reward", "--reward_weights", "1.0", "--sync_ref_model", "True",
+                              "--ref_model_mixup_alpha", "0.6", "--ref_model_sync_steps", "2"])
+
+    def processing_fn(ex):
+        frames = torch.randint(0, 256, (2, 3, 56, 56), generator=torch.Generator().manual_seed(ex["vid"]), dtype=torch.uint8).numpy()
+        px, grid = pixels_from_frames(frames, cfg.vision)
+        tv = grid[0] * grid[1] * grid[2] // 4
+        ids = [40 + ex["vid"], cfg.vision_start_token_id] + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 50, 51]
+        return dict(input_ids=np.asarray(ids), pixel_values_videos=torch.from_numpy(px).cuda(), video_grid_thw=[grid], second_per_grid_ts=[1.0],
+                    decode=lambda toks: ["<think>t</think> <answer>B</answer>" if i % 2 else "nope" for i in range(toks.shape[0])])
+
+    data = [dict(prompt=[{"role": "user", "content": "q"}], assistant="<answer>B</answer>", vid=i) for i in range(4)]
+    funcs, wts, names = rewards.load_reward_funcs("video_r2_amd.rewards", args)
+    tr = QwenGRPOTrainer(m, funcs, args, data, processing_fn, reward_weights=wts, reward_func_names=names)
+    steps = list(tr.iter_steps())
+    ref0 = {k: v.clone() for k, v in tr.ref_params.t.items()}
+    tr.step(steps[0])
+    assert all(torch.equal(tr.ref_params.t[k], ref0[k]) for k in ref0)              # step 1: not a sync step
+    tr.step(steps[1])
+    m.engine.sync()
+    moved = 0
+    for k in ("l0.qkv_w", "l1.down_w", "lm_head", "embed", "l0.ln1", "norm", "l1.qkv_b"):
+        want = 0.4 * ref0[k].float() + 0.6 * m.text.t[k].float()
+        err = (tr.ref_params.t[k].float() - want).abs().max().item()
+        assert err <= 2 ** -8 * want.abs().max().item(), (k, err)                    # one bf16 rounding of the fp32 mix
+        moved += int(not torch.equal(tr.ref_params.t[k], ref0[k]))
+    assert moved >= 4                                                                # the policy had moved (lr 1e-2), so did the reference
+
+
 def _dp_worker(rank, world, port, q, backend="gloo"):
     import os
     local = rank if backend == "nccl" else 0                     # RCCL wants one GPU per rank; the gloo rehearsal shares GPU 0

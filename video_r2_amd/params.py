@@ -51,6 +51,9 @@ class GRPOArguments:
     loss_type: str = "bnpo"
     scale_rewards: bool = True
     mask_truncated_completions: bool = False
+    sync_ref_model: bool = False      # TRL GRPOConfig: every ref_model_sync_steps steps ref <- alpha * policy + (1 - alpha) * ref
+    ref_model_mixup_alpha: float = 0.6   # (SyncRefModelCallback, reached at grpo_trainer.py:587-588)
+    ref_model_sync_steps: int = 512
     per_device_train_batch_size: int = 1
     gradient_accumulation_steps: int = 1
     max_completion_length: int = 256

@@ -359,7 +359,24 @@ class QwenGRPOTrainer:
         if getattr(a, "log_completions", False) and self.global_step % max(1, a.logging_steps) == 0:
             self._log_completions(step_examples, rollouts, adv)
         self.global_step += 1
+        if getattr(a, "sync_ref_model", False) and self.ref_params is not None and self.global_step % max(1, a.ref_model_sync_steps) == 0:
+            self.sync_ref_model(a.ref_model_mixup_alpha)
         return dict(loss=red["loss"], rollouts=rollouts, advantages=adv, metrics=red, update=self.update)
+
+    def sync_ref_model(self, alpha):
+        """TRL's SyncRefModelCallback (--sync_ref_model, grpo_trainer.py:587-588): ref <- alpha * policy + (1 - alpha) * ref on every
+        parameter, every ref_model_sync_steps optimiser steps.  Elementwise, so it runs on the tile-packed bf16 copies as they are
+        (the mix in fp32, one rounding); replicas apply it to identical weights and stay identical.  The reference model's fp8
+        copies (config 5) are re-derived."""
+        eng = self.model.engine
+        with torch.cuda.stream(eng.stream):
+            for k, r in self.ref_params.t.items():
+                p = self.model.text.t.get(k)
+                if p is None or p.shape != r.shape or p.dtype != r.dtype:
+                    continue
+                r.copy_(r.float().mul_(1.0 - alpha).add_(p.float(), alpha=alpha).to(r.dtype))
+            if getattr(self.ref_params, "f8", None):
+                vw.add_fp8_decode_copies(self.ref_params)
 
     def _log_completions(self, examples, rollouts, adv):
         """prompt / completion / reward rows of this step on rank 0 (grpo_trainer.py:1016-1019, :1206-1227: console table)"""
@@ -414,6 +431,8 @@ class QwenGRPOTrainer:
             st = self.updater.state
             state.update(step_count=st.step_count, master={k: v.cpu() for k, v in st.master.items()},
                          m={k: v.cpu() for k, v in st.m.items()}, v={k: v.cpu() for k, v in st.v.items()})
+        if getattr(self.args, "sync_ref_model", False) and self.ref_params is not None:
+            state["ref"] = {k: v.cpu() for k, v in self.ref_params.t.items()}     # the reference is no longer --model_id's weights
         torch.save(state, os.path.join(d, "trainer_state.pt"))
         return d
 
@@ -430,6 +449,12 @@ class QwenGRPOTrainer:
             for k in st.master:
                 st.master[k].copy_(state["master"][k]); st.m[k].copy_(state["m"][k]); st.v[k].copy_(state["v"][k])
             self.updater.refresh_compute_copies()
+        if "ref" in state and self.ref_params is not None:
+            for k, v in state["ref"].items():
+                if k in self.ref_params.t:
+                    self.ref_params.t[k].copy_(v)
+            if getattr(self.ref_params, "f8", None):
+                vw.add_fp8_decode_copies(self.ref_params)
         return self
 
     def log(self):

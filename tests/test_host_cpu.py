@@ -367,3 +367,32 @@ def test_phase_timer_reports_host_phases_under_the_reference_metric_names():
     with off.phase("x"), off.host("y"):
         pass
     assert off.collect() == {}
+
+
+def test_reasoning_reward_gets_the_local_judge_and_tar_rewards_the_sentence_model():
+    """the keyword contract of the reference's reward loop (grpo_trainer.py:866-892): a function named reasoning_reward is called with
+    reward_tokenizer= / reward_model= (the --reward_llm_judge LM), the Temporal-Alignment family with sentence_model=, every other
+    function with neither; the judge is only LOADED when reasoning_reward is selected"""
+    from video_r2_amd import rewards
+    from video_r2_amd.trainer import call_reward_funcs
+    seen = {}
+
+    def reasoning_reward(prompts, completions, reward_tokenizer, reward_model, **kw):
+        seen["reasoning"] = (reward_tokenizer, reward_model, "sentence_model" in kw)
+        return [1.0] * len(completions)
+
+    def temporal_reward(prompts, completions, sentence_model, **kw):
+        seen["tar"] = (sentence_model, "reward_model" in kw)
+        return [None] * len(completions)
+
+    def format_reward(prompts, completions, **kw):
+        seen["plain"] = ("sentence_model" in kw, "reward_model" in kw)
+        return [0.5] * len(completions)
+    a = params.parse_args([])
+    exs = [{"prompt": ["p"], "assistant": "x"}]
+    out = call_reward_funcs([reasoning_reward, temporal_reward, format_reward], ["reasoning_reward", "temporal_reward", "format_reward"], exs, [["a", "b"]],
+                            a, sentence_model="SM", reward_judge=("TOK", "LM"))
+    assert seen == {"reasoning": ("TOK", "LM", False), "tar": ("SM", False), "plain": (False, False)}
+    assert out[:, 0].tolist() == [1.0, 1.0] and torch.isnan(out[:, 1]).all() and out[:, 2].tolist() == [0.5, 0.5]
+    assert rewards.load_reward_judge(["accuracy_reward", "format_reward"], "Qwen/Qwen3-0.6B") == (None, None)   # not selected: not loaded
+    assert rewards.load_reward_judge(["reasoning_reward"], "") == (None, None)

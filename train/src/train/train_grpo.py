@@ -111,8 +111,9 @@ def train(argv=None, processing_fn=None, dataset=None):
     funcs, weights, names = rewards.load_reward_funcs(module, args)
     log(f"reward functions {names} (weights {weights}) from {module}")
     sentence_model = rewards.load_sentence_model(names, args.sentence_model_name)
+    reward_judge = rewards.load_reward_judge(names, args.reward_llm_judge)
     trainer = QwenGRPOTrainer(model, funcs, args, dataset, processing_fn, reward_weights=weights, reward_func_names=names,
-                              sentence_model=sentence_model)
+                              sentence_model=sentence_model, reward_judge=reward_judge)
     resume = args.resume_from_checkpoint or (checkpoints(args.output_dir)[-1][1] if checkpoints(args.output_dir) else "")
     if resume:
         trainer.load_checkpoint(resume)

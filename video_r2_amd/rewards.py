@@ -66,6 +66,22 @@ def load_reward_funcs(module_path=None, training_args=None, *, name_pred=lambda 
     return funcs, wts, kept
 
 
+def load_reward_judge(names, path):
+    """The local judge LM of the reference's ``reasoning_reward`` seam (grpo_trainer.py:348-356: AutoTokenizer + AutoModelForCausalLM
+    from --reward_llm_judge, handed to that function as reward_tokenizer= / reward_model=, :877-881) -- loaded only when a function of
+    that name is selected (the reference loads it whenever the flag is set, used or not).  -> (tokenizer, model) or (None, None)."""
+    if "reasoning_reward" not in names or not path:
+        return None, None
+    try:
+        from transformers import AutoModelForCausalLM, AutoTokenizer
+    except ImportError as e:
+        raise RuntimeError("reasoning_reward needs transformers for its judge model (--reward_llm_judge)") from e
+    tok = AutoTokenizer.from_pretrained(path)
+    model = AutoModelForCausalLM.from_pretrained(path, torch_dtype="auto")
+    model.eval()
+    return tok, model
+
+
 def load_sentence_model(names, model_name="all-MiniLM-L6-v2"):
     """The embedding model the TAR rewards score with (grpo_trainer.py:381-387), only when one of them is selected."""
     if not any(n in SENTENCE_MODEL_REWARDS for n in names):

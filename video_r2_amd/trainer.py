@@ -25,10 +25,11 @@ from .train import cosine_lr
 
 
 def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_example, args, sentence_model=None, pool=None, workers=1,
-                      timer=None):
+                      timer=None, reward_judge=(None, None)):
     """The reward loop of the reference (grpo_trainer.py:846-892) for whole prompt groups: one row per completion, in group
     order.  Every dataset column except "prompt" / "completion" is repeated per completion and forwarded, plus the three knobs
-    of :871-875; the TAR family additionally gets sentence_model= (:878-886).  None -> NaN.  -> fp32 [rows, n_funcs] (CPU).
+    of :871-875; the TAR family additionally gets sentence_model= (:882-886), a function named reasoning_reward the local judge
+    LM as reward_tokenizer= / reward_model= (:877-881).  None -> NaN.  -> fp32 [rows, n_funcs] (CPU).
     workers > 1 (--reward_workers): every function is called on `workers` contiguous slices of the rows from a thread pool -- the
     shipped functions score row by row, and the judge-backed ones spend their time in HTTP round trips (two per completion,
     up to 10 s each: temporal_grounding_reward.py:311-317, reward_funcs.py:103-137), which then overlap."""
@@ -50,6 +51,8 @@ def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_examp
     per_row = {k for k, v in kw.items() if isinstance(v, list) and len(v) == n}
     for i, (fn, name) in enumerate(zip(reward_funcs, reward_func_names)):
         extra = {"sentence_model": sentence_model} if name in SENTENCE_MODEL_REWARDS else {}
+        if name == "reasoning_reward":         # the local judge LM of --reward_llm_judge (grpo_trainer.py:877-881)
+            extra = {"reward_tokenizer": reward_judge[0], "reward_model": reward_judge[1]}
 
         def part(a, b, fn=fn, extra=extra):
             sl = {k: (v[a:b] if k in per_row else v) for k, v in kw.items()}
@@ -72,7 +75,7 @@ def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_examp
 
 class QwenGRPOTrainer:
     def __init__(self, model: VideoR2Model, reward_funcs, args, train_dataset, processing_fn, reward_weights=None,
-                 reward_func_names=None, ref_params=None, sentence_model=None):
+                 reward_func_names=None, ref_params=None, sentence_model=None, reward_judge=(None, None)):
         """processing_fn(example) -> dict(input_ids 1-D int array (unpadded prompt), second_per_grid_ts,
         decode(completion_ids) -> list[str], and the clip(s) as ONE of: videos = [(uint8 frames [n,3,H,W], (H', W'))] (resize
         + normalise + patchify on the device: host/frontend.py ProcessingFrontEnd), video_frames_u8 (already resized),
@@ -94,6 +97,7 @@ class QwenGRPOTrainer:
         self.global_step = 0
         self.num_input_tokens_seen = 0
         self.sentence_model = sentence_model
+        self.reward_judge = reward_judge          # (tokenizer, causal LM) for a reasoning_reward function, else (None, None)
         # HF generate's warpers / processor the reference forwards (grpo_trainer.py:559-570): applied by the decode sampler
         self.sampling = dict(top_p=getattr(args, "top_p", 1.0), min_p=getattr(args, "min_p", None),
                              repetition_penalty=getattr(args, "repetition_penalty", 1.0))
@@ -244,7 +248,7 @@ class QwenGRPOTrainer:
             from concurrent.futures import ThreadPoolExecutor
             self._row_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vr2-reward-rows")
         return call_reward_funcs(self.reward_funcs, self.reward_func_names, examples, texts, self.args, self.sentence_model,
-                                 pool=self._row_pool, workers=workers, timer=self.prof)
+                                 pool=self._row_pool, workers=workers, timer=self.prof, reward_judge=self.reward_judge)
 
     # ------------------------------------------------------------------ one optimisation step (forward half)
     def step(self, step_examples, processed=None):

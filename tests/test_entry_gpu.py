@@ -77,10 +77,16 @@ def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
     for d in (out_dir, out_dir / "checkpoint-2"):
         assert (d / "model.safetensors").exists() and (d / "config.json").exists() and (d / "generation_config.json").exists()
     assert (out_dir / "checkpoint-2" / "trainer_state.pt").exists()
+    # HF Trainer's bookkeeping files: the log history in trainer_state.json (final directory and checkpoints), the metrics stream
+    st = json.loads((out_dir / "trainer_state.json").read_text())
+    assert st["global_step"] == 3 and [r["step"] for r in st["log_history"]] == [1, 2, 3] and "reward" in st["log_history"][0]
+    assert json.loads((out_dir / "checkpoint-2" / "trainer_state.json").read_text())["global_step"] == 2
+    assert len((out_dir / "runs" / "metrics.jsonl").read_text().splitlines()) == 3
     # second launch, one more step allowed: resumes after step 2 (steps 3 and 4 run, not 1..4) and keeps --save_total_limit 2
     steps2, err2 = _launch(env, *flags, "--max_steps", "4")
     assert "resumed from" in err2 and "checkpoint-2 at step 2" in err2
     assert [s["step"] for s in steps2] == [3, 4]
+    assert [r["step"] for r in json.loads((out_dir / "trainer_state.json").read_text())["log_history"]] == [1, 2, 3, 4]   # history continued
     assert sorted(p for p in os.listdir(out_dir) if p.startswith("checkpoint-")) == ["checkpoint-2", "checkpoint-4"]
     # the resumed step 3 sees the same prompts and the same sampling seed as the first run's step 3, from the same weights
     assert steps2[0]["completions/mean_length"] == steps[2]["completions/mean_length"]

@@ -60,6 +60,52 @@ def copy_processor_files(model_dir, out_dir):
             shutil.copy2(src, os.path.join(out_dir, name))
 
 
+class MetricsSink:
+    """Where the logged metrics go besides stdout, as HF Trainer does for the reference (`--report_to tensorboard
+    --logging_steps 1`, train_grpo.sh:72-75; `trainer.save_state()` train_grpo.py:189): event files under
+    output_dir/runs/ when torch.utils.tensorboard imports (it is not in every image), always output_dir/runs/metrics.jsonl, and
+    the log history that HF keeps in trainer_state.json (also written into every checkpoint)."""
+
+    def __init__(self, output_dir, report_to, log, resume=""):
+        self.history = []
+        prev = os.path.join(resume, "trainer_state.json") if resume else ""
+        if prev and os.path.exists(prev):          # a resumed run continues the checkpoint's log history, as HF Trainer does
+            import json
+            self.history = list(json.load(open(prev)).get("log_history", []))
+        self.dir = os.path.join(output_dir, "runs")
+        os.makedirs(self.dir, exist_ok=True)
+        self.jsonl = open(os.path.join(self.dir, "metrics.jsonl"), "a")
+        self.tb = None
+        if "tensorboard" in str(report_to):
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.tb = SummaryWriter(log_dir=self.dir)
+            except Exception as e:        # noqa: BLE001 -- the package is optional; the run must not depend on it
+                log(f"--report_to tensorboard: torch.utils.tensorboard is not importable here ({type(e).__name__}); metrics go to "
+                    f"{self.dir}/metrics.jsonl and trainer_state.json")
+
+    def write(self, row):
+        import json
+        self.history.append(row)
+        self.jsonl.write(json.dumps(row) + "\n")
+        self.jsonl.flush()
+        if self.tb is not None:
+            for k, v in row.items():
+                if k != "step" and isinstance(v, (int, float)):
+                    self.tb.add_scalar("train/" + k, v, row["step"])
+
+    def save_state(self, out_dir, trainer):
+        import json
+        with open(os.path.join(out_dir, "trainer_state.json"), "w") as f:
+            json.dump({"global_step": trainer.global_step, "max_steps": trainer.total_steps,
+                       "num_input_tokens_seen": trainer.num_input_tokens_seen, "log_history": self.history}, f, indent=1)
+
+    def close(self):
+        self.jsonl.close()
+        if self.tb is not None:
+            self.tb.close()
+
+
 def prefetched(steps, processing_fn, workers):
     """(examples, processed) per step; with workers > 0 the host front end of step i + 1 runs on a thread pool while the GPU
     works on step i (decode libraries and PIL release the GIL; frames come back in pinned memory)."""
@@ -120,6 +166,7 @@ def train(argv=None, processing_fn=None, dataset=None):
         log(f"resumed from {resume} at step {trainer.global_step}")
     log(f"{trainer.total_steps} optimiser steps, {trainer.groups_per_step} prompt groups x {args.num_generations} completions each")
     save_every = args.save_steps if (args.save_strategy == "steps" and args.save_steps > 0) else 0
+    sink = MetricsSink(args.output_dir, args.report_to, log, resume) if rank == 0 else None
     t0 = time.time()
     for examples, processed in prefetched(trainer.iter_steps(), processing_fn, args.dataloader_num_workers):
         if trainer.global_step >= trainer.total_steps:
@@ -127,12 +174,15 @@ def train(argv=None, processing_fn=None, dataset=None):
         trainer.step(examples, processed)
         step = trainer.global_step
         if rank == 0 and (step % max(1, args.logging_steps) == 0 or step == trainer.total_steps):
-            print({"step": step, "epoch": round(step / max(1, trainer.steps_per_epoch * max(1, args.num_iterations)), 4),
-                   "elapsed_s": round(time.time() - t0, 1), **trainer.log()}, flush=True)
+            row = {"step": step, "epoch": round(step / max(1, trainer.steps_per_epoch * max(1, args.num_iterations)), 4),
+                   "elapsed_s": round(time.time() - t0, 1), **trainer.log()}
+            print(row, flush=True)
+            sink.write(row)
         if save_every and step % save_every == 0:
             if rank == 0:                                   # replicas are bit-identical: one writer
                 path = trainer.save_checkpoint(args.output_dir)
                 copy_processor_files(args.model_id, path)
+                sink.save_state(path, trainer)
                 prune_checkpoints(args.output_dir, args.save_total_limit)
                 log(f"saved {path}")
             if world > 1:
@@ -141,6 +191,8 @@ def train(argv=None, processing_fn=None, dataset=None):
     if rank == 0:
         model.save_pretrained(args.output_dir)
         copy_processor_files(args.model_id, args.output_dir)
+        sink.save_state(args.output_dir, trainer)          # trainer.save_state() of the reference (train_grpo.py:189)
+        sink.close()
         log(f"final weights in {args.output_dir}")
     if world > 1:
         import torch.distributed as dist

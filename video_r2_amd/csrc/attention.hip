@@ -366,6 +366,37 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
   int lives = (step[0] + 1 + chunk - 1) / chunk;
   if (lives > nslot - npc) lives = nslot - npc;
   const int nlive = livep + lives;
+  const int d = lane * 2;
+  if (nlive <= 8) {
+    // the usual case (a handful of live chunks): every lane reads all the chunks' (m, l) pairs itself -- the same addresses in every
+    // lane, one broadcast load each -- and its two output dims of every chunk in the same batch of loads: ONE memory round trip, no
+    // LDS, no shuffles (the two-pass form below waits for the maxima before it issues the value loads)
+    float2 ml[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = j < livep ? j : npc + (j - livep);
+      const bool on = j < nlive;
+      ml[j] = on ? *reinterpret_cast<const float2*>(pml + (base + c) * 2) : make_float2(-INFINITY, 0.f);
+      v[j] = (on && d < HD) ? *reinterpret_cast<const float2*>(po + (base + c) * HD + d) : make_float2(0.f, 0.f);
+    }
+    float Mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Mx = fmaxf(Mx, ml[j].x);
+    float Ls = 0.f, A0 = 0.f, A1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {       // chunk order, as the general path: the sums do not depend on which path ran
+      const float wv = (ml[j].x == -INFINITY) ? 0.f : __expf(ml[j].x - Mx);
+      Ls += ml[j].y * wv;
+      if (wv != 0.f) { A0 += wv * v[j].x; A1 += wv * v[j].y; }
+    }
+    if (d < HD) {
+      const float inv = Ls > 0.f ? 1.0f / Ls : 0.f;
+      typedef __attribute__((ext_vector_type(2))) __bf16 vb2;
+      vb2 ov = {f2bf(A0 * inv), f2bf(A1 * inv)};
+      *reinterpret_cast<vb2*>(out + (long)g * ldo + (long)head * HD + d) = ov;
+    }
+    return;
+  }
   float M = -INFINITY;
   for (int j = lane; j < nlive; j += 64) {
     const int c = j < livep ? j : npc + (j - livep);
@@ -374,7 +405,6 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
   float L = 0.f, O0 = 0.f, O1 = 0.f;
-  const int d = lane * 2;
   for (int j0 = 0; j0 < nlive; j0 += 64) {
     const int j = j0 + lane;
     float wv = 0.f;

@@ -26,7 +26,10 @@ __device__ __forceinline__ float4 row_update(float* xr, int i, const float* part
   return v;
 }
 
-template <bool REG>
+// SB = split-K slabs read per batch of loads (4 column groups each): 4 for the general kernel; 8 for the decode rows behind an
+// 8-part projection (down): all 32 slab loads of a thread are then in flight at once -- one memory round trip instead of two for
+// a launch that is a latency chain -- at 128 more registers, which the M-row training launches should not pay (own instantiation)
+template <bool REG, int SB = 4>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* __restrict__ x, long ldx, const float* __restrict__ partial,
                                                           long split_stride, long ldp, int nsplit,
                                                           const float* __restrict__ bias, const float* __restrict__ w,
@@ -50,10 +53,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* __restrict__ x,
     if (partial) {
       // split-K slabs: 4 slabs x 4 column groups = 16 independent 16-byte loads in flight per thread (at 64 decode rows and
       // 16 slabs a one-load-at-a-time loop was 15 us per call); summed in slab order, so the result does not depend on timing
-      for (int s0 = 0; s0 < nsplit; s0 += 4) {
-        float4 pv[4][4];
+      for (int s0 = 0; s0 < nsplit; s0 += SB) {
+        float4 pv[SB][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < SB; ++j)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const int i = threadIdx.x * 4 + it * 1024;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(float* __restrict__ x,
                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < SB; ++j)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             keep[it].x += pv[j][it].x; keep[it].y += pv[j][it].y; keep[it].z += pv[j][it].z; keep[it].w += pv[j][it].w;
@@ -370,7 +373,11 @@ extern "C" int vr2_add_rmsnorm(void* x_f32, int64_t ldx, const void* partial_f32
   VR2_REQUIRE(M >= 1 && H >= 4 && H % 4 == 0, "vr2_add_rmsnorm: bad shape M=%ld H=%ld", (long)M, (long)H);
   VR2_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldp % 4 == 0 && split_stride % 4 == 0, "vr2_add_rmsnorm: strides must be multiples of 4");
   VR2_REQUIRE(y_bf16 == nullptr || w_f32 != nullptr, "vr2_add_rmsnorm: norm weight missing");
-  if (H <= 4096)
+  if (H <= 4096 && partial_f32 != nullptr && nsplit > 4 && M <= 256)
+    hipLaunchKernelGGL((add_rmsnorm_kernel<true, 8>), dim3((unsigned)M), dim3(256), 0, STREAM, (float*)x_f32, (long)ldx,
+                       (const float*)partial_f32, (long)split_stride, (long)ldp, nsplit, (const float*)bias_f32,
+                       (const float*)w_f32, (bf16*)y_bf16, (long)ldy, (int)H, eps, (unsigned char*)nullptr, 0L, (float*)nullptr);
+  else if (H <= 4096)
     hipLaunchKernelGGL(add_rmsnorm_kernel<true>, dim3((unsigned)M), dim3(256), 0, STREAM, (float*)x_f32, (long)ldx,
                        (const float*)partial_f32, (long)split_stride, (long)ldp, nsplit, (const float*)bias_f32,
                        (const float*)w_f32, (bf16*)y_bf16, (long)ldy, (int)H, eps, (unsigned char*)nullptr, 0L, (float*)nullptr);

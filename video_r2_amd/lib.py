@@ -11,7 +11,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "vr2.h")
-LIBPATH = os.path.join(HERE, "libvr2.so")
+LIBPATH = os.environ.get("VR2_LIBPATH") or os.path.join(HERE, "libvr2.so")     # (the override: A/B runs of two builds on one box)
 
 _CT = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,

@@ -137,6 +137,92 @@ def case_forward(name, cfg, seed, n_frames, hw, sec, C, pad_left=0, note=""):
     return m, w, p
 
 
+def hf_image_pixels(image_u8_hwc):
+    """pixel_values / grid of ONE still image from HF's own image processor (the PIL backend: the torchvision one cannot be
+    imported here), resizing off: the reference resizes in fetch_image (vision_process.py:374-422) and hands the processor
+    a frame that is already a multiple of 28 inside its pixel range."""
+    from PIL import Image
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    out = Qwen2VLImageProcessorPil(do_resize=False)(images=[Image.fromarray(image_u8_hwc)], return_tensors="np")
+    return out["pixel_values"].astype(np.float32), tuple(int(x) for x in out["image_grid_thw"][0])
+
+
+def case_forward_images(name, cfg, seed, image_hws, video, C, pad_left=0, note=""):
+    """Still images in the prompt (the `images=` half of the reference's processor call, grpo_trainer.py:759-767; dataset rows
+    with an "image" key, grpo_dataset.py:113-125), optionally followed by a video: HF forward with pixel_values / image_grid_thw
+    (+ pixel_values_videos / video_grid_thw), the oracle restatement checked against it, inputs + HF outputs stored.
+    video = (n_frames, (H, W), second_per_grid_t) or None."""
+    w = om.make_weights(cfg, seed=seed)
+    m = hf_model(cfg, w)
+    g = torch.Generator().manual_seed(seed + 1)
+    lo, hi = 10, min(cfg.text.vocab_size, cfg.image_token_id) - 1
+    txt = lambda n: torch.randint(lo, hi, (n,), generator=g).tolist()
+    unit = cfg.vision.spatial_merge_size ** 2
+    ids, images, ipx, igrids = txt(3), [], [], []
+    for (H, W) in image_hws:
+        img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8).numpy()
+        px, grid = hf_image_pixels(img)
+        o_px, o_grid = vi.patchify(vi.normalize_frames(img.transpose(2, 0, 1)[None].astype(np.float32)), cfg.vision.patch_size,
+                                   cfg.vision.spatial_merge_size, cfg.vision.temporal_patch_size)
+        assert tuple(o_grid) == grid and np.abs(o_px - px).max() < 1e-6, (name, "image patchify", np.abs(o_px - px).max())
+        images.append(img); ipx.append(px); igrids.append(grid)
+        ids += [cfg.vision_start_token_id] + [cfg.image_token_id] * (grid[0] * grid[1] * grid[2] // unit) + [cfg.vision_end_token_id] + txt(2)
+    vpx = vgrid = frames = None
+    sec = 1.0
+    if video is not None:
+        n_frames, (H, W), sec = video
+        frames = torch.randint(0, 256, (n_frames, 3, H, W), generator=g, dtype=torch.uint8).float().numpy()
+        vpx, vg = vi.patchify(vi.normalize_frames(frames), cfg.vision.patch_size, cfg.vision.spatial_merge_size, cfg.vision.temporal_patch_size)
+        vgrid = np.asarray([vg], dtype=np.int64)
+        ids += [cfg.vision_start_token_id] + [cfg.video_token_id] * (vg[0] * vg[1] * vg[2] // unit) + [cfg.vision_end_token_id]
+    ids += txt(6)
+    mask = [0] * pad_left + [1] * len(ids)
+    ids = [cfg.pad_token_id] * pad_left + ids
+    comp = torch.randint(lo, hi, (1, C), generator=g)
+    ids = torch.cat([torch.tensor([ids]), comp], 1)
+    am = torch.cat([torch.tensor([mask]), torch.ones(1, C, dtype=torch.long)], 1)
+    ipx_all = np.concatenate(ipx, 0)
+    igrid = np.asarray(igrids, dtype=np.int64)
+    kw = dict(pixel_values=torch.from_numpy(ipx_all), image_grid_thw=torch.from_numpy(igrid))
+    if video is not None:
+        kw.update(pixel_values_videos=torch.from_numpy(vpx.astype(np.float32)), video_grid_thw=torch.from_numpy(vgrid),
+                  second_per_grid_ts=torch.tensor([sec], dtype=torch.float32))
+    with torch.no_grad():
+        hf_logits = m(input_ids=ids, attention_mask=am, mm_token_type_ids=mm_types(cfg, ids), **kw).logits.float()
+        hf_pos, hf_delta = m.model.get_rope_index(ids, mm_types(cfg, ids), image_grid_thw=kw["image_grid_thw"],
+                                                  video_grid_thw=kw.get("video_grid_thw"),
+                                                  second_per_grid_ts=kw.get("second_per_grid_ts"), attention_mask=am)
+        hf_image_embeds = m.model.visual(kw["pixel_values"], grid_thw=kw["image_grid_thw"]).pooler_output
+    T = 0.9
+    lg = hf_logits[:, :-1, :][:, -C:] / T
+    tgt = ids[:, 1:][:, -C:]
+    hf_logps = torch.gather(lg, -1, tgt[..., None]).squeeze(-1) - torch.logsumexp(lg, -1)
+    mm = dict(pixel_values=kw["pixel_values"], image_grid_thw=igrid, pixel_values_videos=kw.get("pixel_values_videos"),
+              video_grid_thw=vgrid, second_per_grid_ts=None if video is None else [sec])
+    o_logps = om.per_token_logps(w, cfg, ids, am.numpy(), C, T, **mm)
+    o_embeds = om.vision_forward(w, cfg, kw["pixel_values"], igrid)
+    o_pos, o_delta = vi.rope_index(ids.numpy(), am.numpy(), vgrid, mm["second_per_grid_ts"], video_token_id=cfg.video_token_id,
+                                   image_token_id=cfg.image_token_id, image_grid_thw=igrid,
+                                   tokens_per_second=cfg.vision.tokens_per_second)
+    valid = am[0].bool()
+    e_vis = (o_embeds - hf_image_embeds).abs().max().item()
+    e_lp = (o_logps - hf_logps).abs().max().item()
+    pos_ok = bool((torch.from_numpy(o_pos)[:, 0, valid] == hf_pos[:, 0, valid]).all()) and int(o_delta[0, 0]) == int(hf_delta[0, 0])
+    print(f"[{name}] image embeds {e_vis:.2e} logps {e_lp:.2e} pos_ok {pos_ok} delta {int(hf_delta[0, 0])} {note}")
+    assert e_vis < 2e-4 and e_lp < 2e-4 and pos_ok, name
+    extra = {}
+    if video is not None:
+        extra = dict(frames_u8=frames.astype(np.uint8), video_grid_thw=vgrid, sec=np.float32(sec))
+    for k, img in enumerate(images):
+        extra[f"image{k}_u8"] = img                                             # HWC uint8, already a multiple of 28
+    np.savez_compressed(
+        os.path.join(GOLD, f"{name}.npz"), seed=np.int64(seed), C=np.int64(C), n_images=np.int64(len(images)),
+        group=np.int64(cfg.text.num_attention_heads // cfg.text.num_key_value_heads),
+        pixel_values=ipx_all, image_grid_thw=igrid, input_ids=ids.numpy(), attention_mask=am.numpy(), temperature=np.float32(T),
+        hf_position_ids=hf_pos.numpy(), hf_rope_delta=hf_delta.numpy(), hf_image_embeds=hf_image_embeds.numpy().astype(np.float32),
+        hf_logps=hf_logps.numpy().astype(np.float32), hf_last_logits=hf_logits[0, -1].numpy().astype(np.float32), **extra)
+
+
 def case_generate(name, cfg, seed, n_frames, hw, G, C):
     """HF generate(do_sample, T=.9, top_k=50) -> token ids; oracle teacher-forced on those ids must reproduce the
     per-step logits (RNG streams differ between HF/torch.multinomial and anything else)."""
@@ -226,6 +312,10 @@ def main():
     case_forward("fwd_tiny_g2_frac", om.cfg_tiny(2), seed=14, n_frames=4, hw=(56, 56), sec=1.5, C=4,
                  note="(fractional second_per_grid_ts: 5.15 semantics int() truncation)")
     case_generate("gen_tiny_g2", om.cfg_tiny(2), seed=21, n_frames=4, hw=(112, 112), G=3, C=12)
+    case_forward_images("fwd_tiny_g2_img", om.cfg_tiny(2), seed=31, image_hws=[(84, 112)], video=(4, (56, 84), 1.0), C=7,
+                        note="(one still image, then a video)")
+    case_forward_images("fwd_tiny_g2_img2", om.cfg_tiny(2), seed=32, image_hws=[(140, 84), (56, 56)], video=None, C=5, pad_left=3,
+                        note="(two still images, no video, left pad)")
 
 
 if __name__ == "__main__":

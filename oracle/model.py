@@ -302,10 +302,17 @@ def lm_head_weight(w, cfg):
     return w["model.embed_tokens.weight"] if cfg.text.tie_word_embeddings else w["lm_head.weight"]
 
 
-def build_inputs_embeds(w, cfg: Cfg, input_ids, video_embeds):
-    """HF:1206-1223: embedding lookup + masked_scatter of the merged video tokens."""
+def build_inputs_embeds(w, cfg: Cfg, input_ids, video_embeds, image_embeds=None):
+    """HF:1206-1223: embedding lookup + masked_scatter of the merged image tokens (image pad positions), then of the merged
+    video tokens (video pad positions)."""
     ids = torch.as_tensor(input_ids)
     emb = w["model.embed_tokens.weight"][ids].clone()
+    if image_embeds is not None:
+        imask = ids == cfg.image_token_id
+        if int(imask.sum()) != image_embeds.shape[0]:
+            raise ValueError(f"Image features and image tokens do not match, tokens: {int(imask.sum())}, "
+                             f"features: {image_embeds.shape[0]}")
+        emb[imask] = image_embeds.to(emb.dtype)
     mask = ids == cfg.video_token_id
     if video_embeds is not None:
         if int(mask.sum()) != video_embeds.shape[0]:
@@ -316,16 +323,20 @@ def build_inputs_embeds(w, cfg: Cfg, input_ids, video_embeds):
 
 
 def forward_logits(w, cfg: Cfg, input_ids, attention_mask, pixel_values_videos, video_grid_thw, second_per_grid_ts,
-                   video_embeds=None, emulate_bf16=False):
-    """Full forward -> logits [B,S,V] fp32 (HF:1308-1402 without the loss)."""
+                   video_embeds=None, emulate_bf16=False, pixel_values=None, image_grid_thw=None, image_embeds=None):
+    """Full forward -> logits [B,S,V] fp32 (HF:1308-1402 without the loss).  Still images (pixel_values, image_grid_thw: the
+    `images=` half of the reference's processor call, grpo_trainer.py:759-767) go through the same vision tower in a pass of
+    their own, as HF's get_image_features does."""
     ids = torch.as_tensor(input_ids)
     if video_embeds is None and pixel_values_videos is not None:
         video_embeds = vision_forward(w, cfg, pixel_values_videos, video_grid_thw, emulate_bf16=emulate_bf16)
-    emb = build_inputs_embeds(w, cfg, ids, video_embeds)
+    if image_embeds is None and pixel_values is not None:
+        image_embeds = vision_forward(w, cfg, pixel_values, image_grid_thw, emulate_bf16=emulate_bf16)
+    emb = build_inputs_embeds(w, cfg, ids, video_embeds, image_embeds)
     am = None if attention_mask is None else np.asarray(attention_mask)
     pos, _ = vi.rope_index(ids.numpy(), am, video_grid_thw, second_per_grid_ts, video_token_id=cfg.video_token_id,
-                           image_token_id=cfg.image_token_id, merge_size=cfg.vision.spatial_merge_size,
-                           tokens_per_second=cfg.vision.tokens_per_second)
+                           image_token_id=cfg.image_token_id, image_grid_thw=image_grid_thw,
+                           merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
     h = lm_forward(w, cfg, emb, torch.from_numpy(pos), None if attention_mask is None else torch.as_tensor(attention_mask),
                    emulate_bf16=emulate_bf16)
     logits = h @ lm_head_weight(w, cfg).t()
@@ -343,7 +354,9 @@ def per_token_logps(w, cfg, input_ids, attention_mask, logits_to_keep, temperatu
     ids = torch.as_tensor(input_ids)
     emu = bool(mm.get("emulate_bf16", False))
     logits = forward_logits(w, cfg, ids, attention_mask, mm.get("pixel_values_videos"), mm.get("video_grid_thw"),
-                            mm.get("second_per_grid_ts"), video_embeds=mm.get("video_embeds"), emulate_bf16=emu)
+                            mm.get("second_per_grid_ts"), video_embeds=mm.get("video_embeds"), emulate_bf16=emu,
+                            pixel_values=mm.get("pixel_values"), image_grid_thw=mm.get("image_grid_thw"),
+                            image_embeds=mm.get("image_embeds"))
     logits = logits[:, :-1, :]
     tgt = ids[:, 1:]
     logits = logits[:, -logits_to_keep:]

@@ -633,3 +633,89 @@ def test_batched_vision_and_prefill_equal_the_one_by_one_path(golden_dir):
     lp = eng.score(eng.text, st, cmp_[None, :], float(f["temperature"]))
     eng.sync()
     assert rel_err(lp.cpu().numpy(), f["hf_logps"]).max() < LOGP_TOL
+
+
+# ---------------------------------------------------------------------------------------------- still images in the prompt
+def _image_items(f, cfg, device_side):
+    """the fixture's vision items in prompt order -> (clips for Engine.encode_videos, second_per_grid_ts with None at images)"""
+    clips, secs = [], []
+    at = 0
+    for k in range(int(f["n_images"])):
+        g = tuple(int(x) for x in f["image_grid_thw"][k])
+        n = g[0] * g[1] * g[2]
+        if device_side:       # uint8 frame -> rescale + normalise + patchify on the device (one frame fills both temporal slots)
+            img = f[f"image{k}_u8"]
+            clips.append(dict(frames_u8=torch.from_numpy(img.transpose(2, 0, 1)[None].copy()), resize_to=None))
+        else:                 # HF's own pixel_values (image processor output)
+            clips.append(dict(pixel_values=torch.from_numpy(f["pixel_values"][at:at + n]), grid=g))
+        at += n
+        secs.append(None)
+    if "frames_u8" in f:
+        px, grid = pixels_from_frames(f["frames_u8"], cfg.vision)
+        clips.append(dict(frames_u8=torch.from_numpy(f["frames_u8"]), resize_to=None) if device_side
+                     else dict(pixel_values=torch.from_numpy(px), grid=grid))
+        secs.append(float(f["sec"]))
+    return clips, secs
+
+
+@pytest.mark.parametrize("name", ["fwd_tiny_g2_img", "fwd_tiny_g2_img2"])
+@pytest.mark.parametrize("device_side", [False, True])
+def test_still_images_in_the_prompt_vs_hf_golden(golden_dir, name, device_side):
+    """Prompts with still images (dataset rows with an "image" key, the `images=` half of the reference's processor call,
+    grpo_trainer.py:759-767): image-pad tokens take the tower's output for a (1, h, w) grid, M-RoPE treats the block as HF's
+    get_rope_index does, images and a clip share one pass of the vision tower.  HF outputs: tests/golden (make_golden.py
+    case_forward_images, pixel_values from HF's own image processor)."""
+    f = _load(golden_dir, name)
+    ocfg = om.cfg_tiny(int(f["group"]))
+    eng, w, cfg = make_engine(ocfg, int(f["seed"]))
+    ids, am = f["input_ids"][0], f["attention_mask"][0].astype(bool)
+    C = int(f["C"])
+    seq = ids[am]
+    prompt, comp = seq[:-C], seq[-C:]
+    clips, secs = _image_items(f, cfg, device_side)
+    (emb, plan), = eng.encode_videos(clips, per_prompt=[len(clips)])
+    st = eng.prefill(eng.text, prompt, emb, plan, secs)
+    lp = eng.score(eng.text, st, comp[None, :], float(f["temperature"]))
+    eng.sync()
+    assert st.rope_delta == int(f["hf_rope_delta"][0, 0])
+    # the image rows of the tower's output, back in natural order, against HF's get_image_features
+    n_img = f["hf_image_embeds"].shape[0]
+    nat = torch.empty_like(emb)
+    nat[torch.from_numpy(plan.window_index).to(emb.device)] = emb
+    ref = f["hf_image_embeds"]
+    e = np.abs(nat[:n_img].cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert e < 2e-2, e
+    r = rel_err(lp.cpu().numpy()[0], f["hf_logps"][0])
+    print(name, "device patchify" if device_side else "HF pixel_values", "logp rel err max", r.max())
+    assert r.max() < LOGP_TOL, r.max()
+    # the batched prefill (one row space for several prompts) lays the same prompt out the same way
+    slots = eng.prefix_slots(2, len(prompt) + 3, tag="pol")
+    (emb2, plan2), (emb3, plan3) = eng.encode_videos(clips + clips, per_prompt=[len(clips), len(clips)])
+    sts = eng.prefill_batch(eng.text, [(prompt, emb2, plan2, secs), (prompt, emb3, plan3, secs)], slots, tag="pol")
+    lp2 = eng.score(eng.text, sts[1], comp[None, :], float(f["temperature"]))
+    eng.sync()
+    assert sts[1].rope_delta == st.rope_delta and rel_err(lp2.cpu().numpy()[0], f["hf_logps"][0]).max() < LOGP_TOL
+
+
+def test_vision_items_out_of_order_or_missing_are_refused():
+    ocfg = om.cfg_tiny(2)
+    eng, w, cfg = make_engine(ocfg, 3)
+    g = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (1, 3, 56, 56), generator=g, dtype=torch.uint8)
+    vid = torch.randint(0, 256, (2, 3, 56, 84), generator=g, dtype=torch.uint8)
+    clips = [dict(frames_u8=img, resize_to=None), dict(frames_u8=vid, resize_to=None)]
+    (emb, plan), = eng.encode_videos(clips, per_prompt=[2])
+    ti, tv = 4, 6
+    ids = np.asarray([5, cfg.vision_start_token_id] + [cfg.image_token_id] * ti + [cfg.vision_end_token_id, 6, cfg.vision_start_token_id]
+                     + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 7])
+    st = eng.prefill(eng.text, ids, emb, plan, [None, 1.0])
+    assert st.n_prompt == len(ids)
+    with pytest.raises(ValueError, match="do not match"):             # kinds swapped: the pad-token counts per kind no longer fit
+        eng.prefill(eng.text, ids, emb, plan, [1.0, None])
+    # same token counts per kind, items in the other order than the prompt's pad-token runs
+    ids2 = np.asarray([5, cfg.vision_start_token_id] + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 6, cfg.vision_start_token_id]
+                      + [cfg.image_token_id] * ti + [cfg.vision_end_token_id, 7])
+    with pytest.raises(ValueError, match="not in prompt order"):
+        eng.prefill(eng.text, ids2, emb, plan, [None, 1.0])
+    with pytest.raises(ValueError, match="do not match"):
+        eng.prefill(eng.text, ids[:-3], emb, plan, [None, 1.0])

@@ -215,3 +215,81 @@ def test_eval_frame_plan_two_stage_selection():
     # a short clip: 4 stage-one frames, 6 wanted -> repeats, as indexing with the reference's linspace does
     idx, _, _ = eval_frame_plan(ele, 8, 4.0, 56, 84, 6)
     assert len(idx) == 6 and len(set(idx.tolist())) < 6 and idx[-1] == 7
+
+
+def test_image_rows_go_through_the_reference_image_stages(tmp_path):
+    """dataset rows with an "image" key (grpo_dataset.py:113-125) -> image elements -> fetch_image's stages
+    (vision_process.py:374-422: RGB with alpha on white, smart_resize under the element's pixel range, PIL resize) -> one
+    uint8 frame per image, image-pad tokens (one per merged patch), None as the item's second_per_grid_ts entry"""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    rgba = rng.integers(0, 256, size=(100, 150, 4), dtype=np.uint8)
+    (tmp_path / "imgs").mkdir()
+    Image.fromarray(rgba, mode="RGBA").save(tmp_path / "imgs" / "a.png")
+    grey = rng.integers(0, 256, size=(64, 64), dtype=np.uint8)
+    Image.fromarray(grey, mode="L").save(tmp_path / "imgs" / "b.png")
+    rows = [{"image": ["a.png", "b.png"], "conversations": [{"from": "human", "value": "<image>\n<image>\nWhat differs?"},
+                                                              {"from": "gpt", "value": "<answer>A</answer>"}]}]
+    path = tmp_path / "d.json"
+    path.write_text(json.dumps(rows))
+    a = params.parse_args(["--data_path", str(path), "--image_folder", str(tmp_path / "imgs"), "--image_min_pixels", str(4 * 28 * 28),
+                           "--image_max_pixels", str(16 * 28 * 28)])
+    ex = hd.make_grpo_data_module("m", None, a)["train_dataset"][0]
+    e0, e1, text = ex["prompt"][1]["content"]
+    assert e0 == {"type": "image", "image": str(tmp_path / "imgs" / "a.png"), "min_pixels": 3136, "max_pixels": 12544}
+    assert text == {"type": "text", "text": "What differs?"}                      # both "<image>\n" tags removed
+    cfg = ModelConfig.tiny()
+    tok = fe.ByteTokenizer(cfg)
+    out = fe.ProcessingFrontEnd(cfg, tok)(ex)
+    (f0, d0), (f1, d1) = out["videos"]
+    assert d0 is None and d1 is None and out["second_per_grid_ts"] == [None, None]
+    # the same stages with PIL called directly, as the reference calls it
+    h0, w0 = hf.smart_resize(100, 150, min_pixels=3136, max_pixels=12544)
+    assert (h0, w0) == (84, 112) and f0.shape == (1, 3, 84, 112) and f0.dtype == torch.uint8
+    bg = Image.new("RGB", (150, 100), (255, 255, 255))
+    im = Image.fromarray(rgba, mode="RGBA")
+    bg.paste(im, mask=im.split()[3])
+    want0 = np.asarray(bg.resize((w0, h0)))
+    assert np.array_equal(f0[0].permute(1, 2, 0).numpy(), want0)
+    h1, w1 = hf.smart_resize(64, 64, min_pixels=3136, max_pixels=12544)
+    want1 = np.asarray(Image.fromarray(grey, mode="L").convert("RGB").resize((w1, h1)))
+    assert (h1, w1) == (56, 56) and np.array_equal(f1[0].permute(1, 2, 0).numpy(), want1)
+    ids = out["input_ids"].tolist()
+    n0, n1 = (84 // 14) * (112 // 14) // 4, (56 // 14) * (56 // 14) // 4
+    assert ids.count(cfg.image_token_id) == n0 + n1 and ids.count(cfg.video_token_id) == 0
+    at = ids.index(cfg.image_token_id)
+    assert ids[at - 1] == cfg.vision_start_token_id and ids[at + n0] == cfg.vision_end_token_id
+    assert ids[at + n0 + 1] == cfg.vision_start_token_id and ids[at + n0 + 2 + n1] == cfg.vision_end_token_id
+    # fixed output size: snapped to a multiple of 28, the pixel range not consulted
+    fixed = fe.read_image({"image": str(tmp_path / "imgs" / "b.png"), "resized_height": 100, "resized_width": 70})
+    assert fixed.shape == (1, 3, 112, 56)                        # 70 / 28 = 2.5 rounds half to even, as round() in the reference
+    # data URI and PIL object sources
+    import base64, io
+    buf = io.BytesIO(); Image.fromarray(grey, mode="L").save(buf, format="PNG")
+    uri = "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+    assert torch.equal(fe.read_image({"image": uri, "min_pixels": 3136, "max_pixels": 12544}), f1)
+    assert torch.equal(fe.read_image({"image": Image.fromarray(grey, mode="L"), "min_pixels": 3136, "max_pixels": 12544}), f1)
+
+
+def test_mixed_image_and_video_prompt_keeps_prompt_order(tmp_path, monkeypatch):
+    monkeypatch.delenv("WRITE_TIMESTAMPS_ON_FRAMES", raising=False)
+    monkeypatch.delenv("WRITE_SUBTITLES_ON_FRAMES", raising=False)
+    from PIL import Image
+    _clip(tmp_path, t=60, h=56, w=84, fps=30.0)
+    Image.fromarray(np.random.default_rng(1).integers(0, 256, size=(56, 56, 3), dtype=np.uint8)).save(tmp_path / "i.png")
+    cfg = ModelConfig.tiny()
+    pf = fe.ProcessingFrontEnd(cfg, fe.ByteTokenizer(cfg))
+    vid = {"type": "video", "video": str(tmp_path / "a.npz"), "fps": 2.0, "min_pixels": 56 * 84, "max_pixels": 56 * 84, "subtitles": None}
+    img = {"type": "image", "image": str(tmp_path / "i.png"), "min_pixels": 3136, "max_pixels": 3136}
+    out = pf({"prompt": [{"role": "user", "content": [vid, img, {"type": "text", "text": "?"}]}]})
+    ids = out["input_ids"]
+    first_vid, first_img = int(np.flatnonzero(ids == cfg.video_token_id)[0]), int(np.flatnonzero(ids == cfg.image_token_id)[0])
+    assert first_vid < first_img and out["second_per_grid_ts"][1] is None and out["second_per_grid_ts"][0] is not None
+    assert out["videos"][0][0].shape[0] == 4 and out["videos"][1][0].shape == (1, 3, 56, 56)
+    # the engine-side layout of exactly this prompt (host/rope_index.vision_layout): items consumed in prompt order
+    from video_r2_amd.host import rope_index as ri
+    grids = [(2, 4, 6), (1, 4, 4)]
+    pos, delta, vis = ri.vision_layout(ids, cfg.video_token_id, cfg.image_token_id, grids, out["second_per_grid_ts"])
+    assert len(vis) == 12 + 4 and pos.shape == (3, len(ids))
+    with pytest.raises(ValueError, match="not in prompt order"):
+        ri.vision_layout(ids, cfg.video_token_id, cfg.image_token_id, grids[::-1], out["second_per_grid_ts"][::-1])

@@ -158,7 +158,7 @@ def test_generate_with_hf_keyword_arguments_as_the_eval_harness_calls_it():
         if not near:   # bf16-level logit noise can move a token across a warper's boundary: accept it within 2e-2 of the kept set's edge
             edge = kept[torch.isfinite(kept)].min()
             assert float(edge - raw[0, tok] / 0.7) < 5e-2, (j, tok)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="do not match"):          # image features without image tokens (HF's masked_scatter check)
         m.generate(**kw, pixel_values=torch.zeros(4, 1176), max_new_tokens=2)
 
 
@@ -511,3 +511,46 @@ def test_rccl_loads_and_runs_collectives_next_to_the_engine_library():
     a, b, c = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0 and a == 12345.0 and b == 3.5 and c == 7.0
+
+
+def test_facade_takes_image_inputs_like_hf(golden_dir):
+    """generate / per_token_logps with the `images=` half of the processor output (pixel_values, image_grid_thw) beside the video
+    half, as the reference forwards **prompt_inputs (grpo_trainer.py:759-786, :723-741): log-probs against the HF golden vectors,
+    copies of one sample recognised as a group, greedy generate == a direct engine decode of the same prompt."""
+    import os
+    from oracle import model as om
+    from tests.helpers import to_engine_cfg, pixels_from_frames, rel_err
+    from video_r2_amd import weights as W
+    from video_r2_amd.model import VideoR2Model
+    for name in ("fwd_tiny_g2_img", "fwd_tiny_g2_img2"):
+        f = np.load(os.path.join(golden_dir, name + ".npz"))
+        ocfg = om.cfg_tiny(int(f["group"]))
+        cfg = to_engine_cfg(ocfg)
+        m = VideoR2Model.from_state_dict(cfg, om.make_weights(ocfg, seed=int(f["seed"])))
+        C = int(f["C"])
+        ids, am = torch.from_numpy(f["input_ids"]), torch.from_numpy(f["attention_mask"])
+        mm = dict(pixel_values=torch.from_numpy(f["pixel_values"]), image_grid_thw=torch.from_numpy(f["image_grid_thw"]))
+        if "frames_u8" in f:
+            px, grid = pixels_from_frames(f["frames_u8"], cfg.vision)
+            mm.update(pixel_values_videos=torch.from_numpy(px), video_grid_thw=torch.tensor([grid]), second_per_grid_ts=[float(f["sec"])])
+        # two copies of the sample in one batch (the reference batches G copies): every tensor repeated per row
+        rep = {k: (torch.cat([v, v], 0) if torch.is_tensor(v) else list(v) * 2) for k, v in mm.items()}
+        lp = m.per_token_logps(torch.cat([ids, ids], 0), torch.cat([am, am], 0), C, temperature=float(f["temperature"]), **rep)
+        m.engine.sync()
+        for b in range(2):
+            r = rel_err(lp[b].cpu().numpy(), f["hf_logps"][0])
+            assert r.max() < 1e-3, (name, b, r.max())
+        P = ids.shape[1] - C
+        out = m.generate(ids[:, :P], am[:, :P], max_new_tokens=6, do_sample=False, **mm)
+        assert out.shape == (1, P + 6) and bool((out[:, :P].cpu() == ids[:, :P]).all())
+        # the same prompt through the engine directly
+        media = m._media(ids[:, :P].numpy(), am[:, :P].numpy(), mm["pixel_values"], mm["image_grid_thw"], mm.get("pixel_values_videos"),
+                         mm.get("video_grid_thw"), mm.get("second_per_grid_ts"))
+        emb, plan, sec = m._encode_group(media, 0)
+        st = m.engine.prefill(m.text, ids[0, :P][am[0, :P].bool()].numpy(), emb, plan, sec)
+        toks, _ = m.engine.decode(m.text, st, 1, 6, temperature=1.0, top_k=1, seed=0, eos_token_id=cfg.eos_token_id)
+        m.engine.sync()
+        assert bool((out[0, P:].cpu() == toks[0].cpu().long()).all())
+    # image tokens without image features: HF's error, not a silent text prompt
+    with pytest.raises(ValueError, match="do not match|no image pixel values"):
+        m.per_token_logps(ids, am, C, image_grid_thw=None, pixel_values=None)

@@ -219,3 +219,34 @@ def test_oracle_warpers_match_hf_logits_processors():
     for pen in (1.3, 0.8):
         want = lp.RepetitionPenaltyLogitsProcessor(penalty=pen)(ids, x.clone())
         assert torch.equal(om.repetition_penalty(x, ids, pen), want)
+
+
+@pytest.mark.parametrize("name", ["fwd_tiny_g2_img", "fwd_tiny_g2_img2"])
+def test_image_prompts_oracle_and_host_layout_vs_hf_golden(golden_dir, name):
+    """still images in the prompt (make_golden.py case_forward_images: HF forward with pixel_values / image_grid_thw): the oracle
+    restatement reproduces HF's log-probs, the product's host-side layout (vision_layout: items in prompt order, None marks an
+    image) reproduces HF's M-RoPE ids bit for bit, the image patchify equals HF's image processor output"""
+    import os
+    from oracle import model as om
+    from video_r2_amd.host import rope_index as ri
+    f = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = om.cfg_tiny(int(f["group"]))
+    w = om.make_weights(cfg, seed=int(f["seed"]))
+    ids, am = f["input_ids"], f["attention_mask"]
+    mm = dict(pixel_values=torch.from_numpy(f["pixel_values"]), image_grid_thw=f["image_grid_thw"])
+    grids, secs = [tuple(int(x) for x in g) for g in f["image_grid_thw"]], [None] * int(f["n_images"])
+    if "frames_u8" in f:
+        px, grid = ovi.patchify(ovi.normalize_frames(f["frames_u8"].astype(np.float32)))
+        mm.update(pixel_values_videos=torch.from_numpy(px.astype(np.float32)), video_grid_thw=f["video_grid_thw"], second_per_grid_ts=[float(f["sec"])])
+        grids.append(tuple(int(x) for x in f["video_grid_thw"][0])); secs.append(float(f["sec"]))
+    lp = om.per_token_logps(w, cfg, torch.from_numpy(ids), am, int(f["C"]), float(f["temperature"]), **mm).numpy()
+    assert np.abs(lp - f["hf_logps"]).max() < 2e-4
+    keep = am[0].astype(bool)
+    pos, delta, vis = ri.vision_layout(ids[0][keep], cfg.video_token_id, cfg.image_token_id, grids, secs)
+    assert np.array_equal(pos, f["hf_position_ids"][:, 0][:, keep]) and delta == int(f["hf_rope_delta"][0, 0])
+    at = 0
+    for k in range(int(f["n_images"])):
+        img = f[f"image{k}_u8"]
+        px, g = ovi.patchify(ovi.normalize_frames(img.transpose(2, 0, 1)[None].astype(np.float32)))
+        assert tuple(g) == grids[k] and np.abs(px - f["pixel_values"][at:at + len(px)]).max() < 1e-6      # HF normalises in two steps
+        at += len(px)

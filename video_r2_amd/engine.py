@@ -459,31 +459,37 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ prompt prefill (K8-K12)
+    def vision_layout(self, ids, plan, second_per_grid_ts, embeds):
+        """M-RoPE positions, rope delta and the prompt positions of the vision tokens for one unpadded prompt whose vision items
+        (plan.grid_thw, in prompt order) are video clips and / or still images -- an item is a STILL IMAGE when its
+        second_per_grid_ts entry is None (host/rope_index.vision_layout).  Raises HF's "... features and ... tokens do not match"."""
+        cfg = self.cfg
+        grids = [] if plan is None else plan.grid_thw
+        pos, delta, vis_pos = ri.vision_layout(ids, cfg.video_token_id, cfg.image_token_id, grids, second_per_grid_ts,
+                                               merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
+        if embeds is not None and vis_pos.shape[0] != embeds.shape[0]:
+            raise ValueError(f"Video features and video tokens do not match, tokens: {vis_pos.shape[0]}, features: {embeds.shape[0]}")
+        if embeds is None and vis_pos.shape[0]:
+            raise ValueError("prompt has video tokens but no video features were given")
+        return pos, delta, vis_pos
+
     @_on_stream
     def prefill(self, W: Params, input_ids, video_embeds, plan, second_per_grid_ts, tag="pol", prefix_out=None) -> PromptState:
-        """input_ids: 1-D unpadded prompt (host ints).  video_embeds: window-ordered merged tokens from encode_video.
+        """input_ids: 1-D unpadded prompt (host ints).  video_embeds: window-ordered merged tokens from encode_video /
+        encode_videos over the prompt's vision items in prompt order; second_per_grid_ts: one entry per item, None = still image.
         prefix_out = (k, v) tensors [L][>=S][nkv*hd] to write the prompt KV into (one slot of a multi-group batch)."""
         cfg, t = self.cfg, self.cfg.text
         ids = np.asarray(input_ids, dtype=np.int64).reshape(-1)
         S = int(ids.shape[0])
-        grids = [] if plan is None else plan.grid_thw
-        pos, delta = ri.rope_index_1seq(ids, cfg.video_token_id, cfg.image_token_id, grids, second_per_grid_ts,
-                                        merge_size=cfg.vision.spatial_merge_size,
-                                        tokens_per_second=cfg.vision.tokens_per_second)
+        pos, delta, vid_pos = self.vision_layout(ids, plan, second_per_grid_ts, video_embeds)
         H, hd, nkv = t.hidden_size, t.head_dim, t.num_key_value_heads
         d_ids = _i32(ids, self.device)
         x = self.buf(tag + ".px", (S, H), torch.float32)
         lib.call("vr2_embed_rows", d_ids, W["embed"], W["embed"].stride(0), x, x.stride(0), S, H, self.s)
-        vid_pos = np.flatnonzero(ids == cfg.video_token_id)
         if video_embeds is not None:
-            if vid_pos.shape[0] != video_embeds.shape[0]:
-                raise ValueError(f"Video features and video tokens do not match, tokens: {vid_pos.shape[0]}, "
-                                 f"features: {video_embeds.shape[0]}")
             # row i of the window-ordered merger output is natural token window_index[i] (HF :464-466)
             dst = _i32(vid_pos[plan.window_index], self.device)
             lib.call("vr2_scatter_rows_f32", video_embeds, video_embeds.stride(0), dst, x, x.stride(0), vid_pos.shape[0], H, self.s)
-        elif vid_pos.shape[0]:
-            raise ValueError("prompt has video tokens but no video features were given")
         d_pos = _i32(pos, self.device)
         cos = self.buf(tag + ".pcos", (S, hd // 2), torch.float32)
         sin = self.buf(tag + ".psin", (S, hd // 2), torch.float32)
@@ -535,29 +541,24 @@ class Engine:
         T = P * rp
         ids_all = np.full((P, rp), cfg.pad_token_id, dtype=np.int64)
         pos_all = np.zeros((3, P, rp), dtype=np.int64)
-        deltas, works = [], []
+        deltas, works, vis_pos = [], [], []
         for p_, ((_, emb, plan, sec), ids) in enumerate(zip(prompts, idss)):
             S = len(ids)
             ids_all[p_, :S] = ids
-            grids = [] if plan is None else plan.grid_thw
-            pos, delta = ri.rope_index_1seq(ids, cfg.video_token_id, cfg.image_token_id, grids, sec,
-                                            merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
+            pos, delta, vis = self.vision_layout(ids, plan, sec, emb)
             pos_all[:, p_, :S] = pos
             deltas.append(delta)
+            vis_pos.append(vis)
             # queries = this prompt's rows of the batch; keys = its own cache slot, causal (row index relative to slot 0 of the layer)
             works.append(vp.causal_work(S, p_ * rp, 0, 0, p_ * gstride, q_tile=vp.LM_Q_TILE))
         x = self.buf(tag + ".bx", (T, H), torch.float32)
         d_ids = _i32(ids_all.reshape(-1), self.device)
         lib.call("vr2_embed_rows", d_ids, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, self.s)
         for p_, ((_, emb, plan, _), ids) in enumerate(zip(prompts, idss)):
-            vid_pos = np.flatnonzero(ids == cfg.video_token_id)
             if emb is not None:
-                if vid_pos.shape[0] != emb.shape[0]:
-                    raise ValueError(f"Video features and video tokens do not match, tokens: {vid_pos.shape[0]}, features: {emb.shape[0]}")
+                vid_pos = vis_pos[p_]
                 dst = _i32(p_ * rp + vid_pos[plan.window_index], self.device)
                 lib.call("vr2_scatter_rows_f32", emb, emb.stride(0), dst, x, x.stride(0), vid_pos.shape[0], H, self.s)
-            elif vid_pos.shape[0]:
-                raise ValueError("prompt has video tokens but no video features were given")
         cos = self.buf(tag + ".bcos", (T, hd // 2), torch.float32)
         sin = self.buf(tag + ".bsin", (T, hd // 2), torch.float32)
         lib.call("vr2_mrope_table", _i32(pos_all.reshape(3, T), self.device), T, self.inv_freq, self.section, cos, sin, hd, self.s)

@@ -15,12 +15,14 @@ plain class with the same methods, which is what tests/test_eval_adapter_gpu.py 
 """
 from __future__ import annotations
 
+import re
+
 import numpy as np
 import torch
 
 from .host import frames as hf
 from .host import processor as hp
-from .host.frontend import (VIDEO_PAD, ProcessingFrontEnd, frame_range, load_tokenizer, open_clip, render_chat)
+from .host.frontend import (IMAGE_PAD, VIDEO_PAD, ProcessingFrontEnd, frame_range, load_tokenizer, open_clip, read_image, render_chat)
 
 VIDEO_SUFFIXES = (".mp4", ".avi", ".mov", ".mkv", ".webm", ".npy", ".npz", ".pt")
 
@@ -120,7 +122,7 @@ class VideoR2EvalModel:
         context = context.replace("<image>", "")
         if self.reasoning_prompt:
             context = context.strip() + self.reasoning_prompt
-        content, clips, secs, counts = [], [], [], []
+        content, clips, secs, counts, pads = [], [], [], [], []
         for v in visuals:
             if isinstance(v, str) and v.lower().endswith(VIDEO_SUFFIXES):
                 ele = self._video_element(v)
@@ -129,17 +131,35 @@ class VideoR2EvalModel:
                 clips.append(dict(frames_u8=frames, resize_to=dims))
                 secs.append(hp.second_per_grid_t(cfg.vision.temporal_patch_size, sfps))
                 counts.append(self.front.video_tokens(frames.shape[0], *dims))
-            else:
-                raise NotImplementedError(f"visual of type {type(v).__name__}: the engine adapter takes video files only (images are "
-                                          "outside the rollout path this build covers)")
+                pads.append(cfg.video_token_id)
+            elif hasattr(v, "convert") and hasattr(v, "save"):
+                # a PIL image: the harness sends it as an RGB JPEG data URI (qwen2_5_vl.py:239-245), so the model sees the JPEG
+                # round trip's pixels, resized by fetch_image under the adapter's pixel range
+                import base64
+                import io
+                buf = io.BytesIO()
+                v.convert("RGB").save(buf, format="JPEG")
+                ele = {"type": "image", "image": "data:image/jpeg;base64," + base64.b64encode(buf.getvalue()).decode("utf-8"),
+                       "max_pixels": self.max_pixels, "min_pixels": self.min_pixels}
+                frame = read_image(ele)
+                content.append(ele)
+                clips.append(dict(frames_u8=frame, resize_to=None))
+                secs.append(None)                                        # None = still image
+                counts.append(self.front.video_tokens(1, int(frame.shape[2]), int(frame.shape[3])))
+                pads.append(cfg.image_token_id)
+            else:     # (the harness class drops such a visual without a word and answers from the text alone: refused here instead)
+                raise NotImplementedError(f"visual of type {type(v).__name__}: the adapter takes video files ({', '.join(VIDEO_SUFFIXES)}) "
+                                          "and PIL images, as the reference's model class does")
         messages = [{"role": "system", "content": self.system_prompt},
                     {"role": "user", "content": content + [{"type": "text", "text": context}]}]
-        pieces = render_chat(messages, add_generation_prompt=True).split(VIDEO_PAD)
-        ids = []
-        for k, piece in enumerate(pieces):
-            ids.extend(self._tokenizer.encode(piece))
-            if k < len(clips):
-                ids.extend([cfg.video_token_id] * counts[k])
+        pieces = re.split("(" + re.escape(VIDEO_PAD) + "|" + re.escape(IMAGE_PAD) + ")", render_chat(messages, add_generation_prompt=True))
+        ids, k = [], 0
+        for j, piece in enumerate(pieces):
+            if j % 2 == 0:
+                ids.extend(self._tokenizer.encode(piece))
+            else:
+                ids.extend([pads[k]] * counts[k])
+                k += 1
         return np.asarray(ids, dtype=np.int64), clips, secs or None, context
 
     def _answers(self, prepared, gen_kwargs):

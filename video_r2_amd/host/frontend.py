@@ -7,6 +7,10 @@ chat template -> `process_vision_info` (read video, pick frames, burn timestamps
     {"input_ids": int64 [S] (unpadded prompt), "videos": [(uint8 frames [n,3,H,W], (H', W') to resize to), ...],
      "second_per_grid_ts": [float, ...], "decode": callable(completion ids [G,C]) -> list[str]}
 
+("videos" = the prompt's vision items in prompt order: a still image -- dataset rows with an "image" key, grpo_dataset.py:113-125,
+the `images=` half of the processor call -- is an item of ONE frame, already resized by PIL as `fetch_image` does it, with None
+as its second_per_grid_ts entry and <|image_pad|> tokens in the prompt)
+
 and the uint8 frames go to the device as they are: the antialiased bicubic resize, rescale + normalise and patchify run there
 (Engine.resize_frames / encode_frames, bit-identical to torchvision + the HF video processor).  Host-side pieces, each after
 the reference lines it follows:
@@ -341,6 +345,61 @@ def read_video(ele, clip=None):
     return frames, hf.sample_fps(n, total, fps), dims
 
 
+# ---------------------------------------------------------------------------------------------- still images
+PROCESSOR_MIN_PIXELS, PROCESSOR_MAX_PIXELS = 56 * 56, 28 * 28 * 16384      # Qwen2.5-VL preprocessor_config.json (min / max_pixels)
+
+
+def open_image(src):
+    """PIL image from what an image element may hold (vision_process.py:374-400): a PIL image, a path, file://, http(s)://
+    or a data:image;base64 URI."""
+    from PIL import Image
+    if isinstance(src, Image.Image):
+        return src
+    if isinstance(src, np.ndarray):
+        return Image.fromarray(src)
+    if src.startswith("http://") or src.startswith("https://"):
+        import io
+        import urllib.request
+        with urllib.request.urlopen(src, timeout=10) as r:
+            return Image.open(io.BytesIO(r.read())).copy()
+    if src.startswith("data:image") and "base64," in src:
+        import base64
+        import io
+        return Image.open(io.BytesIO(base64.b64decode(src.split("base64,", 1)[1]))).copy()
+    return Image.open(src[7:] if src.startswith("file://") else src)
+
+
+def to_rgb(img):
+    """alpha composited on white, everything else converted (vision_process.py:365-371)"""
+    from PIL import Image
+    if img.mode == "RGBA":
+        bg = Image.new("RGB", img.size, (255, 255, 255))
+        bg.paste(img, mask=img.split()[3])
+        return bg
+    return img.convert("RGB")
+
+
+def read_image(ele, processor_pixels=(PROCESSOR_MIN_PIXELS, PROCESSOR_MAX_PIXELS)):
+    """One still-image element -> uint8 frame [1,3,H',W'] ready for the device (rescale + normalise + patchify there; the single
+    frame fills both temporal slots of its patches, as HF's image processor repeats it).  The reference's two host stages:
+    `fetch_image` (vision_process.py:401-420: RGB, smart_resize under the element's min / max pixels -- or the given
+    resized_height / resized_width snapped to 28 -- then PIL's resize with its default filter) and the HF image processor's own
+    smart_resize under the PROCESSOR's pixel range (a no-op for an image that is already inside it)."""
+    from PIL import Image
+    img = to_rgb(open_image(ele["image"] if "image" in ele else ele["image_url"]))
+    if "resized_height" in ele and "resized_width" in ele:
+        h, w = hf.smart_resize(ele["resized_height"], ele["resized_width"], factor=hf.IMAGE_FACTOR)
+    else:
+        w0, h0 = img.size
+        h, w = hf.smart_resize(h0, w0, factor=hf.IMAGE_FACTOR, min_pixels=ele.get("min_pixels", hf.MIN_PIXELS),
+                               max_pixels=ele.get("max_pixels", hf.MAX_PIXELS))
+    img = img.resize((w, h))
+    h2, w2 = hf.smart_resize(h, w, factor=hf.IMAGE_FACTOR, min_pixels=processor_pixels[0], max_pixels=processor_pixels[1])
+    if (h2, w2) != (h, w):
+        img = img.resize((w2, h2), resample=Image.BICUBIC)
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).unsqueeze(0).contiguous()
+
+
 # ---------------------------------------------------------------------------------------------- chat layout + tokenisers
 def render_chat(messages, add_generation_prompt=True):
     """The Qwen2.5-VL chat layout for the message shapes the dataset builds (system string + user list of media / text
@@ -443,27 +502,37 @@ class ProcessingFrontEnd:
 
     def __call__(self, example):
         prompt = example["prompt"]
-        videos, secs, counts = [], [], []
+        videos, secs, counts, pads = [], [], [], []         # the prompt's vision items in prompt order: clips and still images
         for m in prompt:
             if not isinstance(m["content"], list):
                 continue
             for c in m["content"]:
                 if c.get("type") == "image" or "image" in c or "image_url" in c:
-                    raise NotImplementedError("image elements: the GRPO stage of Video-R2 trains on video rows only")
-                if c.get("type") == "video" or "video" in c:
+                    frame = read_image(c)                    # [1,3,H',W'], already at its final size (PIL, as the reference)
+                    videos.append((frame.pin_memory() if torch.cuda.is_available() else frame, None))
+                    secs.append(None)                        # None = still image (HF has second_per_grid_ts for videos only)
+                    counts.append(self.video_tokens(1, int(frame.shape[2]), int(frame.shape[3])))
+                    pads.append(self.cfg.image_token_id)
+                elif c.get("type") == "video" or "video" in c:
                     frames, sfps, dims = read_video(c, self.open(c["video"]))
                     videos.append((frames.pin_memory() if torch.cuda.is_available() else frames, dims))
                     secs.append(hp.second_per_grid_t(self.cfg.vision.temporal_patch_size, sfps))
                     counts.append(self.video_tokens(frames.shape[0], *dims))
+                    pads.append(self.cfg.video_token_id)
         text = render_chat(prompt, add_generation_prompt=True)
-        pieces = text.split(VIDEO_PAD)
-        if len(pieces) - 1 != len(videos):
-            raise ValueError(f"{len(pieces) - 1} video placeholders in the prompt text but {len(videos)} video elements")
-        ids = []
-        for k, piece in enumerate(pieces):
-            ids.extend(self.tok.encode(piece))
-            if k < len(videos):
-                ids.extend([self.cfg.video_token_id] * counts[k])
+        pieces = re.split("(" + re.escape(VIDEO_PAD) + "|" + re.escape(IMAGE_PAD) + ")", text)
+        marks = [pc for pc in pieces[1::2]]
+        want = [VIDEO_PAD if p_ == self.cfg.video_token_id else IMAGE_PAD for p_ in pads]
+        if marks != want:
+            raise ValueError(f"{marks.count(VIDEO_PAD)} video placeholders and {marks.count(IMAGE_PAD)} image placeholders in the prompt "
+                             f"text but {want.count(VIDEO_PAD)} video and {want.count(IMAGE_PAD)} image elements (or in another order)")
+        ids, k = [], 0
+        for j, piece in enumerate(pieces):
+            if j % 2 == 0:
+                ids.extend(self.tok.encode(piece))
+            else:
+                ids.extend([pads[k]] * counts[k])            # one pad token per merged patch (HF processing_qwen2_5_vl.py:138-154)
+                k += 1
         tok = self.tok
 
         def decode(completion_ids):

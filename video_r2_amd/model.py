@@ -1,7 +1,7 @@
 """Drop-in model façade: the two calls the reference trainer makes on its HF model, served by the MI355X engine.
 
-  * ``generate(input_ids=, attention_mask=, pixel_values_videos=, video_grid_thw=, second_per_grid_ts=, generation_config=)``
-    -> LongTensor [B, S + C]          (/root/reference/train/src/trainer/grpo_trainer.py:783-786)
+  * ``generate(input_ids=, attention_mask=, pixel_values_videos=, video_grid_thw=, second_per_grid_ts=, [pixel_values=,
+    image_grid_thw=,] generation_config=)`` -> LongTensor [B, S + C]   (/root/reference/train/src/trainer/grpo_trainer.py:783-786)
   * ``per_token_logps(input_ids, attention_mask, logits_to_keep, **multimodal_inputs)`` -> [B, C]   (grpo_trainer.py:723-741)
   * ``from_pretrained(path)`` / ``save_pretrained(path)`` in HF layout (train_grpo.py:114-119, :208)
 
@@ -54,6 +54,78 @@ def _groups(ids, mask, same_video=None):
     return out
 
 
+class _Media:
+    """The batch's vision inputs as HF hands them over -- ``pixel_values`` + ``image_grid_thw`` for the still images of ALL rows,
+    ``pixel_values_videos`` + ``video_grid_thw`` (+ ``second_per_grid_ts``) for all the clips, each list in batch-then-prompt
+    order (what `processor(text=, images=, videos=)` returns, grpo_trainer.py:759-767) -- dealt to the rows the way HF's
+    masked_scatter consumes them: row after row, and inside a row one pad-token run after the other."""
+
+    def __init__(self, cfg, ids, mask, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts):
+        self.cfg = cfg
+        self.px = {"image": pixel_values, "video": pixel_values_videos}
+        self.grids, self.offs = {}, {}
+        for kind, g in (("image", image_grid_thw), ("video", video_grid_thw)):
+            g = np.zeros((0, 3), dtype=np.int64) if g is None else np.asarray(g.cpu() if torch.is_tensor(g) else g).reshape(-1, 3)
+            self.grids[kind] = g
+            self.offs[kind] = np.concatenate([[0], np.cumsum(g[:, 0] * g[:, 1] * g[:, 2])]).astype(np.int64)
+        self.secs = None if second_per_grid_ts is None else [float(x) for x in np.asarray(
+            second_per_grid_ts.cpu() if torch.is_tensor(second_per_grid_ts) else second_per_grid_ts).reshape(-1)]
+        unit = cfg.vision.spatial_merge_size ** 2
+        tok_id = {"image": cfg.image_token_id, "video": cfg.video_token_id}
+        cur = {"image": 0, "video": 0}
+        self.items = []                                  # per row: [(kind, index into that kind's grid list)] in prompt order
+        for b in range(ids.shape[0]):
+            row = ids[b][mask[b].astype(bool)]
+            typ = np.where(row == tok_id["video"], 2, np.where(row == tok_id["image"], 1, 0))
+            edges = np.flatnonzero(np.diff(typ)) + 1
+            its = []
+            for a, e in zip(np.concatenate([[0], edges]), np.concatenate([edges, [len(typ)]])):
+                if a == e or typ[a] == 0:
+                    continue
+                kind = "video" if typ[a] == 2 else "image"
+                if self.px[kind] is None:
+                    if kind == "image" and pixel_values_videos is not None:
+                        continue                          # stray image-pad ids in a video prompt: plain tokens, as before
+                    raise ValueError(f"prompt has {kind} tokens but no {kind} pixel values were given")
+                need, tok = int(e - a), 0
+                while tok < need and cur[kind] < len(self.grids[kind]):
+                    g = self.grids[kind][cur[kind]]
+                    tok += int(g[0] * g[1] * g[2]) // unit
+                    its.append((kind, cur[kind]))
+                    cur[kind] += 1
+                if tok != need:
+                    raise ValueError(f"{kind.capitalize()} features and {kind} tokens do not match, tokens: {need}, features: {tok}")
+            self.items.append(its)
+        for kind in ("image", "video"):                  # features nobody asked for: HF's masked_scatter check fails the same way
+            if cur[kind] != len(self.grids[kind]) or (self.px[kind] is not None and len(self.grids[kind]) == 0):
+                left = int(self.offs[kind][-1] - self.offs[kind][cur[kind]]) // unit if len(self.grids[kind]) else int(self.px[kind].shape[0]) // unit
+                raise ValueError(f"{kind.capitalize()} features and {kind} tokens do not match: {left} merged {kind} feature rows are "
+                                 f"left over after the batch's {kind} tokens were served (or no {kind} grid was given)")
+
+    def same(self, b):
+        """row b carries the same vision inputs (kinds, grids and pixel values) as row b - 1: placeholder ids are the same for
+        every item of one geometry, so equal ids alone do not make two rows copies of one sample"""
+        ia, ib = self.items[b - 1], self.items[b]
+        if len(ia) != len(ib):
+            return False
+        for (ka, xa), (kb, xb) in zip(ia, ib):
+            if ka != kb or not np.array_equal(self.grids[ka][xa], self.grids[kb][xb]):
+                return False
+            o, px = self.offs[ka], self.px[ka]
+            if not torch.equal(px[int(o[xa]):int(o[xa + 1])], px[int(o[xb]):int(o[xb + 1])]):
+                return False
+        return True
+
+    def clips(self, b):
+        """-> (clips for Engine.encode_videos, second_per_grid_ts per item with None marking a still image)"""
+        clips, secs = [], []
+        for kind, x in self.items[b]:
+            o = self.offs[kind]
+            clips.append(dict(pixel_values=self.px[kind][int(o[x]):int(o[x + 1])], grid=tuple(int(v) for v in self.grids[kind][x])))
+            secs.append(None if kind == "image" else (1.0 if self.secs is None else self.secs[x]))
+        return clips, secs
+
+
 class VideoR2Model:
     def __init__(self, cfg: ModelConfig, vision: W.Params, text: W.Params, device="cuda:0"):
         self.cfg = cfg
@@ -92,69 +164,29 @@ class VideoR2Model:
                   metadata={"format": "pt"})
 
     # ------------------------------------------------------------------ the two hot calls
-    def _video_slices(self, grid_thw, n_rows):
-        if grid_thw is None:
-            return None
-        g = np.asarray(grid_thw.cpu() if torch.is_tensor(grid_thw) else grid_thw).reshape(-1, 3)
-        sizes = g[:, 0] * g[:, 1] * g[:, 2]
-        offs = np.concatenate([[0], np.cumsum(sizes)])
-        return g, offs
+    def _media(self, ids, mask, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts):
+        return _Media(self.cfg, ids, mask, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts)
 
-    def _same_video_fn(self, ids, mask, pixel_values_videos, grids, offs):
-        """-> same_video(b) for _groups: row b's clips (consumed in order, as many as its video tokens need) equal row b-1's."""
-        if grids is None or pixel_values_videos is None:
-            return None
-        unit = self.cfg.vision.spatial_merge_size ** 2
-        spans, cur = [], 0
-        for b in range(ids.shape[0]):
-            need = int(((ids[b] == self.cfg.video_token_id) & mask[b].astype(bool)).sum())
-            first, tok = cur, 0
-            while tok < need and cur < len(grids):
-                tok += int(grids[cur][0] * grids[cur][1] * grids[cur][2]) // unit
-                cur += 1
-            spans.append((first, cur))
-        px = pixel_values_videos
-
-        def same(b):
-            (a0, a1), (b0, b1) = spans[b - 1], spans[b]
-            if a1 - a0 != b1 - b0 or not np.array_equal(grids[a0:a1], grids[b0:b1]):
-                return False
-            if a1 == a0:
-                return True
-            return bool(torch.equal(px[int(offs[a0]):int(offs[a1])], px[int(offs[b0]):int(offs[b1])]))
-        return same
-
-    def _encode_group(self, row, ids_row, pixel_values_videos, grids, offs, second_per_grid_ts, vid_cursor):
-        cfg = self.cfg
-        n_vid_tok = int((ids_row == cfg.video_token_id).sum())
-        if n_vid_tok == 0 or pixel_values_videos is None:
-            if n_vid_tok:
-                raise ValueError("prompt has video tokens but pixel_values_videos is None")
-            return None, None, None, vid_cursor
-        # videos of this row: consume grids until their merged-token count covers the row's video tokens
-        unit = cfg.vision.spatial_merge_size ** 2
-        take, tok = [], 0
-        while tok < n_vid_tok and vid_cursor + len(take) < len(grids):
-            gi = vid_cursor + len(take)
-            take.append(gi)
-            tok += int(grids[gi][0] * grids[gi][1] * grids[gi][2]) // unit
-        if tok != n_vid_tok:
-            raise ValueError(f"Video features and video tokens do not match, tokens: {n_vid_tok}, features: {tok}")
-        px = pixel_values_videos[int(offs[take[0]]):int(offs[take[-1] + 1])]
-        emb, plan = self.engine.encode_video(px, grids[take])
-        sec = None if second_per_grid_ts is None else [float(second_per_grid_ts[i]) for i in take]
-        return emb, plan, sec, vid_cursor + len(take)
+    def _encode_group(self, media, row):
+        """vision items of batch row ``row`` -> (merged tokens in window order, plan, second_per_grid_ts with None at still
+        images) for Engine.prefill; (None, None, None) for a text-only row"""
+        clips, secs = media.clips(row)
+        if not clips:
+            return None, None, None
+        (emb, plan), = self.engine.encode_videos(clips, per_prompt=[len(clips)])
+        return emb, plan, secs
 
     @torch.no_grad()
     def generate(self, input_ids, attention_mask=None, pixel_values_videos=None, video_grid_thw=None,
-                 second_per_grid_ts=None, generation_config: GenerationConfig | None = None, **hf_kwargs):
+                 second_per_grid_ts=None, generation_config: GenerationConfig | None = None, pixel_values=None,
+                 image_grid_thw=None, **hf_kwargs):
         """Also takes HF ``generate`` keyword arguments in place of a generation_config -- max_new_tokens, do_sample,
         temperature, top_k, top_p, min_p, repetition_penalty, num_beams, eos_token_id, pad_token_id, use_cache -- which is how
         the evaluation harness calls its model (/root/reference/eval/lmms-eval/lmms_eval/models/qwen2_5_vl.py:326-336): greedy
-        when do_sample is false, beams refused (not silently ignored), image inputs refused (video path only).  top_p / min_p run
-        on the top-k candidate set (1 <= top_k <= 64), the repetition penalty over prompt + generated ids, all in HF's order."""
-        if hf_kwargs.get("pixel_values") is not None or hf_kwargs.get("image_grid_thw") is not None:
-            raise NotImplementedError("VideoR2Model.generate: image inputs are not supported (video rollout path only)")
+        when do_sample is false, beams refused (not silently ignored).  Still images (pixel_values, image_grid_thw: the `images=`
+        half of the processor's output, which the trainer forwards with **prompt_inputs, grpo_trainer.py:759-786) run through the
+        same vision tower as the clips.  top_p / min_p run on the top-k candidate set (1 <= top_k <= 64), the repetition penalty
+        over prompt + generated ids, all in HF's order."""
         if generation_config is None:
             gc = GenerationConfig()
             for k in ("max_new_tokens", "do_sample", "top_k", "eos_token_id", "pad_token_id"):
@@ -177,12 +209,10 @@ class VideoR2Model:
         ids = input_ids.cpu().numpy()
         mask = np.ones_like(ids) if attention_mask is None else attention_mask.cpu().numpy()
         B, S = ids.shape
-        vs = self._video_slices(video_grid_thw, B)
-        grids, offs = (vs if vs is not None else (None, None))
+        media = self._media(ids, mask, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts)
         pad = cfg.pad_token_id if gc.pad_token_id is None else gc.pad_token_id
         outs = []
-        vid_cursor = 0
-        groups = list(_groups(ids, mask, self._same_video_fn(ids, mask, pixel_values_videos, grids, offs)))
+        groups = list(_groups(ids, mask, media.same))
         temp = gc.temperature if gc.do_sample else 1.0
         topk = gc.top_k if gc.do_sample else 1
         warp = dict(top_p=gc.top_p if gc.do_sample else 1.0, min_p=gc.min_p if gc.do_sample else None,
@@ -199,11 +229,7 @@ class VideoR2Model:
                 slots = self.engine.prefix_slots(len(chunk), max(len(g_[2]) for g_ in chunk), tag="pol") if len(chunk) > 1 else [None]
                 states = []
                 for p_, (row, n_, ids_row) in enumerate(chunk):
-                    emb, plan, sec, vid_cursor = self._encode_group(row, ids_row, pixel_values_videos, grids, offs, second_per_grid_ts, vid_cursor)
-                    for _ in range(1, n_):
-                        _, _, _, vid_cursor = self._skip(ids_row, grids, vid_cursor)
-                    if emb is not None:
-                        emb = emb.clone()
+                    emb, plan, sec = self._encode_group(media, row)        # the group's copies carry the same inputs: encoded once
                     states.append(self.engine.prefill(self.text, ids_row, emb, plan, sec, tag="pol", prefix_out=slots[p_]))
                 toks, _ = self.engine.decode(self.text, states if len(states) > 1 else states[0], n, gc.max_new_tokens,
                                              temperature=temp, top_k=topk, seed=gc.seed + 7919 * c0, eos_token_id=eos, **warp)
@@ -212,9 +238,7 @@ class VideoR2Model:
         else:
             for gi, (row, n, ids_row) in enumerate(groups):
                 # every row of the batch carries its own copy of the video: encode the first, skip the copies
-                emb, plan, sec, vid_cursor = self._encode_group(row, ids_row, pixel_values_videos, grids, offs, second_per_grid_ts, vid_cursor)
-                for _ in range(1, n):
-                    _, _, _, vid_cursor = self._skip(ids_row, grids, vid_cursor)
+                emb, plan, sec = self._encode_group(media, row)
                 st = self.engine.prefill(self.text, ids_row, emb, plan, sec, tag="pol")
                 toks, _ = self.engine.decode(self.text, st, n, gc.max_new_tokens, temperature=temp, top_k=topk,
                                              seed=gc.seed + 7919 * gi, eos_token_id=eos, **warp)
@@ -226,20 +250,10 @@ class VideoR2Model:
             result[row:row + n, S:S + t.shape[1]] = t.long()
         return result
 
-    def _skip(self, ids_row, grids, vid_cursor):
-        """advance the video cursor past one row's videos without encoding them"""
-        cfg = self.cfg
-        n_vid_tok = int((ids_row == cfg.video_token_id).sum())
-        unit = cfg.vision.spatial_merge_size ** 2
-        tok = 0
-        while grids is not None and tok < n_vid_tok and vid_cursor < len(grids):
-            tok += int(grids[vid_cursor][0] * grids[vid_cursor][1] * grids[vid_cursor][2]) // unit
-            vid_cursor += 1
-        return None, None, None, vid_cursor
-
     @torch.no_grad()
     def per_token_logps(self, input_ids, attention_mask, logits_to_keep, temperature=0.9, text_params=None, tag="pol",
-                        pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None, **_ignored):
+                        pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None, pixel_values=None,
+                        image_grid_thw=None, **_ignored):
         """input_ids [B, P + C] (prompt left-padded, completion right side), attention_mask [B, P + C] ->
         log-probs [B, C] of the last C tokens.  Positions masked out (after EOS) return 0."""
         cfg = self.cfg
@@ -249,14 +263,10 @@ class VideoR2Model:
         B, T = ids.shape
         C = int(logits_to_keep)
         P = T - C
-        vs = self._video_slices(video_grid_thw, B)
-        grids, offs = (vs if vs is not None else (None, None))
+        media = self._media(ids[:, :P], mask[:, :P], pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts)
         out = torch.zeros((B, C), dtype=torch.float32, device=self.device)
-        vid_cursor = 0
-        for gi, (row, n, ids_row) in enumerate(_groups(ids[:, :P], mask[:, :P], self._same_video_fn(ids[:, :P], mask[:, :P], pixel_values_videos, grids, offs))):
-            emb, plan, sec, vid_cursor = self._encode_group(row, ids_row, pixel_values_videos, grids, offs, second_per_grid_ts, vid_cursor)
-            for r in range(1, n):
-                _, _, _, vid_cursor = self._skip(ids_row, grids, vid_cursor)
+        for gi, (row, n, ids_row) in enumerate(_groups(ids[:, :P], mask[:, :P], media.same)):
+            emb, plan, sec = self._encode_group(media, row)
             st = self.engine.prefill(Wt, ids_row, emb, plan, sec, tag=tag)
             comp = torch.from_numpy(ids[row:row + n, P:]).to(self.device)
             lp = self.engine.score(Wt, st, comp, temperature, tag=tag)

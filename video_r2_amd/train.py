@@ -160,9 +160,7 @@ class Trainer:
         seq_len = [C] * G if lay is None else [int(n) for n in lay["lens"]]
         seq_off = [g * C for g in range(G)] if lay is None else [int(o) for o in lay["offs"]]    # first row of a sequence, from S
         T = S + R
-        grids = [] if plan is None else plan.grid_thw
-        pos, delta = ri.rope_index_1seq(ids, cfg.video_token_id, cfg.image_token_id, grids, second_per_grid_ts,
-                                        merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
+        pos, delta, vid_pos = eng.vision_layout(ids, plan, second_per_grid_ts, video_embeds)
         pc = np.concatenate([np.arange(n, dtype=np.int64) + S + delta for n in seq_len])
         pos_all = np.concatenate([pos, np.broadcast_to(pc[None, :], (3, R))], 1)
         d_sel = None if lay is None else torch.from_numpy(lay["sel"]).to(eng.device)
@@ -171,10 +169,7 @@ class Trainer:
         b = eng.buf
         x = b("t.x", (T, H), torch.float32)
         lib.call("vr2_embed_rows", all_ids, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, eng.s)
-        vid_pos = np.flatnonzero(ids == cfg.video_token_id)
         if video_embeds is not None:
-            if vid_pos.shape[0] != video_embeds.shape[0]:
-                raise ValueError(f"Video features and video tokens do not match, tokens: {vid_pos.shape[0]}, features: {video_embeds.shape[0]}")
             dst = _i32(vid_pos[plan.window_index], eng.device)
             lib.call("vr2_scatter_rows_f32", video_embeds, video_embeds.stride(0), dst, x, x.stride(0), vid_pos.shape[0], H, eng.s)
         cos = b("t.cos", (T, hd // 2), torch.float32); sin = b("t.sin", (T, hd // 2), torch.float32)

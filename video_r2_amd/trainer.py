@@ -79,7 +79,8 @@ class QwenGRPOTrainer:
         """processing_fn(example) -> dict(input_ids 1-D int array (unpadded prompt), second_per_grid_ts,
         decode(completion_ids) -> list[str], and the clip(s) as ONE of: videos = [(uint8 frames [n,3,H,W], (H', W'))] (resize
         + normalise + patchify on the device: host/frontend.py ProcessingFrontEnd), video_frames_u8 (already resized),
-        or pixel_values_videos + video_grid_thw (host-processed, as the HF processor returns them)).
+        or pixel_values_videos + video_grid_thw (host-processed, as the HF processor returns them)).  A still image (dataset
+        rows with an "image" key) is an item of `videos` holding ONE frame, with None as its second_per_grid_ts entry.
         The host front end (chat template, frame sampling, overlays) stays Python as in the reference (grpo_trainer.py:755-767)."""
         self.model = model
         self.args = args

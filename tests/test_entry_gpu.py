@@ -100,3 +100,19 @@ def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
     for s in steps3:
         assert np.isfinite(s["loss"]) and s["grad_norm"] > 0
         assert s["profiling/Time taken: QwenGRPOTrainer.generate"] > 0 and "profiling/Time taken: QwenGRPOTrainer.text_length_reward" in s
+    # fourth launch: dataset rows with an "image" key (grpo_dataset.py:113-125) through the same shell entry -- fetch_image's
+    # stages on the host, image-pad tokens, the one-frame vision items beside nothing else in the tower's pass
+    from PIL import Image
+    img_rows = []
+    for i in range(2):
+        Image.fromarray(rng.integers(0, 256, size=(60 + 10 * i, 90, 3), dtype=np.uint8)).save(clips / "set" / f"p{i}.png")
+        img_rows.append({"image": f"set/p{i}.png",
+                         "conversations": [{"from": "human", "value": f"<image>\nQuestion {i} about the picture?\nA. yes\nB. no"},
+                                           {"from": "gpt", "value": "<answer>A</answer>"}], "temporal_grounding": {}})
+    data_img = tmp_path / "grpo_img.json"
+    data_img.write_text(json.dumps(img_rows))
+    env4 = dict(env, OUTPUT_DIR=str(tmp_path / "out_img"), DATA_PATH=str(data_img))
+    steps4, err4 = _launch(env4, *flags, "--max_steps", "2", "--image_min_pixels", "3136", "--image_max_pixels", "4704")
+    assert [s["step"] for s in steps4] == [1, 2], err4[-3000:]
+    for s in steps4:
+        assert np.isfinite(s["loss"]) and s["grad_norm"] > 0 and s["completions/mean_length"] > 0

@@ -152,31 +152,91 @@ __device__ __forceinline__ unsigned radix_select_256(const unsigned (&key)[NK], 
   return prefix;
 }
 
+// The slice's k-th largest key without walking the radix passes over all of its keys.  Each thread's largest key is one of 256
+// DISTINCT elements of the slice, so the k-th largest of those maxima (k <= 256) is a lower bound T0 of the slice's k-th largest
+// key: every top-k key is >= T0, and on anything but degenerate data only a few times k keys are.  Those go to a short LDS list
+// (LCAP entries) on which the exact k-th largest is found by counting ranks; a list that overflows (more than LCAP keys >= T0:
+// long runs of equal logits) falls back to the 4-pass radix select over the registers.  The kept set {key >= thr} is the same
+// either way.  (The radix passes cost 4 x (19 same-address-heavy LDS atomics per thread + a 16-barrier scan): 70 us per token at
+// 128 rows; this form: a maximum, 256 + |list| comparisons per thread and 6 barriers.)
+constexpr int LCAP_SEL = 768;
+
 __global__ __launch_bounds__(256) void topk_candidates_kernel(const float* __restrict__ logits, long ldl, int V, int top_k,
                                                               float* __restrict__ cand_val, int* __restrict__ cand_idx) {
   __shared__ unsigned hist[256];
   __shared__ unsigned bc[2];
   __shared__ int count;
+  __shared__ unsigned lkey[LCAP_SEL];
+  __shared__ int lidx[LCAP_SEL];
+  __shared__ int lcount;
   const int s = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   const int L = (V + NSLICE - 1) / NSLICE;
   const int lo = s * L;
   const int n = (lo + L <= V) ? L : (V - lo > 0 ? V - lo : 0);
   const float* row = logits + (long)g * ldl;
   unsigned key[NJ];
-  int present = 0;
+  unsigned mx = 0u;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int i = tid + 256 * j;
     key[j] = (i < n) ? f2key(row[lo + i]) : 0u;   // f2key never returns 0 for a finite float or +-inf
+    mx = key[j] > mx ? key[j] : mx;
   }
   float* cv = cand_val + ((long)g * NSLICE + s) * CAND;
   int* ci = cand_idx + ((long)g * NSLICE + s) * CAND;
   if (tid < CAND) { cv[tid] = -INFINITY; ci[tid] = 0x7fffffff; }
-  if (tid == 0) count = 0;
-  (void)present;
+  if (tid == 0) { count = 0; lcount = 0; }
   if (n == 0) return;
   const unsigned k = (unsigned)(top_k < n ? top_k : n);
-  const unsigned thr = radix_select_256<NJ>(key, k, hist, bc);
+  unsigned thr;
+  bool listed = false;
+  if (k <= 256u && n >= 256) {
+    // T0 = the k-th largest of the 256 thread maxima: the maximum whose rank interval [#greater, #greater-or-equal) holds k - 1
+    hist[tid] = mx;
+    __syncthreads();
+    unsigned gt = 0u, ge = 0u;
+#pragma unroll 8
+    for (int o = 0; o < 256; ++o) {
+      const unsigned m = hist[o];
+      gt += m > mx;
+      ge += m >= mx;
+    }
+    if (gt < k && k <= ge) bc[0] = mx;             // every thread that satisfies it holds the same value
+    __syncthreads();
+    const unsigned t0 = bc[0];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (key[j] != 0u && key[j] >= t0) {
+        const int slot = atomicAdd(&lcount, 1);
+        if (slot < LCAP_SEL) { lkey[slot] = key[j]; lidx[slot] = lo + tid + 256 * j; }
+      }
+    __syncthreads();
+    const int ln = lcount;
+    listed = ln <= LCAP_SEL;                        // (ln >= k: the k maxima that are >= T0 are in the list)
+    if (listed) {
+      // exact k-th largest of the list by rank counting; LCAP_SEL / 256 entries per thread
+      for (int e = tid; e < ln; e += 256) {
+        const unsigned me = lkey[e];
+        unsigned a = 0u, b = 0u;
+        for (int o = 0; o < ln; ++o) {
+          const unsigned m = lkey[o];
+          a += m > me;
+          b += m >= me;
+        }
+        if (a < k && k <= b) bc[1] = me;
+      }
+      __syncthreads();
+      thr = bc[1];
+      for (int e = tid; e < ln; e += 256)
+        if (lkey[e] >= thr) {
+          const int slot = atomicAdd(&count, 1);
+          if (slot < CAND) { const int i = lidx[e]; cv[slot] = row[i]; ci[slot] = i; }
+        }
+      return;
+    }
+    __syncthreads();                                // overflow: the radix path re-uses hist / bc
+  }
+  thr = radix_select_256<NJ>(key, k, hist, bc);
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     if (key[j] != 0u && key[j] >= thr) {

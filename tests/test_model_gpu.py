@@ -554,3 +554,36 @@ def test_facade_takes_image_inputs_like_hf(golden_dir):
     # image tokens without image features: HF's error, not a silent text prompt
     with pytest.raises(ValueError, match="do not match|no image pixel values"):
         m.per_token_logps(ids, am, C, image_grid_thw=None, pixel_values=None)
+
+
+def test_forward_logits_serves_the_reference_logprob_body_unchanged(golden_dir):
+    """`model(input_ids=, attention_mask=, **multimodal_inputs).logits` -- what the reference's _get_per_token_logps reads
+    (grpo_trainer.py:725-739) -- followed by ITS slicing / temperature / gather - logsumexp: the HF golden log-probs come out,
+    for a left-padded video prompt and for a prompt with still images."""
+    import os
+    from oracle import model as om
+    from tests.helpers import to_engine_cfg, pixels_from_frames, rel_err
+    from video_r2_amd.model import VideoR2Model
+    for name in ("fwd_tiny_g2_pad", "fwd_tiny_g2_img"):
+        f = np.load(os.path.join(golden_dir, name + ".npz"))
+        ocfg = om.cfg_tiny(int(f["group"]))
+        cfg = to_engine_cfg(ocfg)
+        m = VideoR2Model.from_state_dict(cfg, om.make_weights(ocfg, seed=int(f["seed"])))
+        C = int(f["C"])
+        input_ids, attention_mask = torch.from_numpy(f["input_ids"]), torch.from_numpy(f["attention_mask"])
+        px, grid = pixels_from_frames(f["frames_u8"], cfg.vision)
+        mm = dict(pixel_values_videos=torch.from_numpy(px), video_grid_thw=torch.tensor([grid]), second_per_grid_ts=[float(f["sec"])])
+        if "pixel_values" in f:
+            mm.update(pixel_values=torch.from_numpy(f["pixel_values"]), image_grid_thw=torch.from_numpy(f["image_grid_thw"]))
+        # ---- the reference's lines, verbatim in structure
+        logits = m(input_ids=input_ids.to(m.device), attention_mask=attention_mask.to(m.device), **mm).logits
+        logits = logits[:, :-1, :]
+        ids = input_ids[:, 1:].to(m.device)
+        logits = logits[:, -C:]
+        ids = ids[:, -C:]
+        logits = logits / float(f["temperature"])
+        logps = torch.gather(logits, -1, ids.unsqueeze(-1)).squeeze(-1) - torch.logsumexp(logits, dim=-1)
+        r = rel_err(logps[0].cpu().numpy(), f["hf_logps"][0])
+        assert r.max() < 1e-3, (name, r.max())
+        last = m(input_ids=input_ids, attention_mask=attention_mask, **mm).logits[0, -1]
+        assert np.abs(last.cpu().numpy() - f["hf_last_logits"]).max() < 2e-2

@@ -474,7 +474,7 @@ class Engine:
         return pos, delta, vis_pos
 
     @_on_stream
-    def prefill(self, W: Params, input_ids, video_embeds, plan, second_per_grid_ts, tag="pol", prefix_out=None) -> PromptState:
+    def prefill(self, W: Params, input_ids, video_embeds, plan, second_per_grid_ts, tag="pol", prefix_out=None, all_logits=None) -> PromptState:
         """input_ids: 1-D unpadded prompt (host ints).  video_embeds: window-ordered merged tokens from encode_video /
         encode_videos over the prompt's vision items in prompt order; second_per_grid_ts: one entry per item, None = still image.
         prefix_out = (k, v) tensors [L][>=S][nkv*hd] to write the prompt KV into (one slot of a multi-group batch)."""
@@ -507,6 +507,10 @@ class Engine:
         last.copy_(x[S - 1:S])
         logits = self.buf(tag + ".plogits" + slot, (1, t.vocab_size), torch.float32)
         self._logits_rows(W, x[S - 1:S], 1, logits)
+        if all_logits is not None:        # f32 [S, V] of the caller: the logits of EVERY position (HF-style forward().logits)
+            for r0 in range(0, S, 1024):
+                n = min(1024, S - r0)
+                self._logits_rows(W, x[r0:r0 + n], n, all_logits[r0:r0 + n])
         return PromptState(n_prompt=S, rope_delta=delta, prefix_k=pk, prefix_v=pv, last_hidden=last, last_logits=logits, input_ids=ids)
 
     @_on_stream

@@ -272,3 +272,33 @@ class VideoR2Model:
             lp = self.engine.score(Wt, st, comp, temperature, tag=tag)
             out[row:row + n] = lp * torch.from_numpy(mask[row:row + n, P:]).to(self.device, torch.float32)
         return out
+
+    @torch.no_grad()
+    def forward(self, input_ids, attention_mask=None, pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None,
+                pixel_values=None, image_grid_thw=None, text_params=None, **_ignored):
+        """HF-style forward for callers that read ``.logits`` -- the reference's ``_get_per_token_logps`` body as it stands
+        (``model(input_ids=, attention_mask=, **multimodal_inputs).logits`` then slice / temperature / selective_log_softmax,
+        grpo_trainer.py:725-739).  -> an object with ``logits`` f32 [B, T, V] (row t predicts token t + 1; rows at masked
+        positions are zero).  Every batch row runs as one causal sequence of its unmasked tokens; ``per_token_logps`` is the
+        fast path (shared prompt prefix, no [T, V] tensor) -- this one exists so that unmodified trainer code keeps working."""
+        from types import SimpleNamespace
+        Wt = self.text if text_params is None else text_params
+        ids = input_ids.cpu().numpy()
+        mask = np.ones_like(ids) if attention_mask is None else attention_mask.cpu().numpy()
+        B, T = ids.shape
+        V = self.cfg.text.vocab_size
+        media = self._media(ids, mask, pixel_values, image_grid_thw, pixel_values_videos, video_grid_thw, second_per_grid_ts)
+        logits = torch.zeros((B, T, V), dtype=torch.float32, device=self.device)
+        for b in range(B):
+            keep = mask[b].astype(bool)
+            row = ids[b][keep]
+            if row.size == 0:
+                continue
+            emb, plan, sec = self._encode_group(media, b)
+            lg = torch.empty((row.shape[0], V), dtype=torch.float32, device=self.device)
+            self.engine.prefill(Wt, row, emb, plan, sec, tag="fwd", all_logits=lg)
+            logits[b, torch.from_numpy(keep).to(self.device)] = lg
+        self.engine.sync()
+        return SimpleNamespace(logits=logits)
+
+    __call__ = forward

@@ -144,6 +144,15 @@ def test_generate_with_hf_keyword_arguments_as_the_eval_harness_calls_it():
         assert tok == int(top2.indices[j, 0]) or float(top2.values[j, 0] - top2.values[j, 1]) < 2e-2, j
     with pytest.raises(ValueError, match="beam"):
         m.generate(**kw, num_beams=4, max_new_tokens=2)
+    # an HF-shaped generation_config object, as the reference trainer passes it (transformers.GenerationConfig built at
+    # grpo_trainer.py:559-570: HF's attribute names, a LIST of eos ids, no `seed` attribute): read, never modified
+    from types import SimpleNamespace
+    hf_gc = SimpleNamespace(max_new_tokens=C, do_sample=False, temperature=0.9, top_p=1.0, top_k=50, min_p=None, repetition_penalty=1.0,
+                            pad_token_id=cfg.pad_token_id, eos_token_id=[-1], num_beams=1, max_length=None)
+    out3 = m.generate(**kw, generation_config=hf_gc)
+    assert torch.equal(out3, out) and hf_gc.eos_token_id == [-1]
+    with pytest.raises(ValueError, match="beam"):
+        m.generate(**kw, generation_config=SimpleNamespace(max_new_tokens=2, do_sample=False, num_beams=2))
     # sampling with HF's warpers: every drawn token lies in the set the oracle's warpers keep for ITS step (teacher-forced oracle on
     # the engine's own tokens); a repetition penalty > 1 is applied to prompt + generated ids before them
     outs = m.generate(**kw, eos_token_id=-1, pad_token_id=cfg.pad_token_id, do_sample=True, temperature=0.7, top_k=20, top_p=0.8, min_p=0.05,

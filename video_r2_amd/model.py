@@ -200,7 +200,20 @@ class VideoR2Model:
             if "do_sample" in hf_kwargs and not hf_kwargs["do_sample"]:
                 gc.top_p, gc.min_p = 1.0, None                   # HF ignores the warpers without sampling
         else:
-            gc = generation_config
+            # our dataclass or an HF `transformers.GenerationConfig` (what the reference trainer builds, grpo_trainer.py:559-570):
+            # read by attribute name into a config of our own -- the caller's object is never modified, HF's has no `seed`
+            gc = GenerationConfig()
+            for k in ("max_new_tokens", "do_sample", "temperature", "top_p", "top_k", "min_p", "repetition_penalty", "pad_token_id",
+                      "eos_token_id", "seed"):
+                v = getattr(generation_config, k, None)
+                if v is not None:
+                    setattr(gc, k, v)
+            if getattr(generation_config, "max_new_tokens", None) is None and getattr(generation_config, "max_length", None):
+                gc.max_new_tokens = max(1, int(generation_config.max_length) - int(input_ids.shape[1]))   # HF: total length cap
+            if (getattr(generation_config, "num_beams", None) or 1) != 1:
+                raise ValueError(f"num_beams={generation_config.num_beams}: the engine samples or decodes greedily, it has no beam search")
+            if not gc.do_sample:
+                gc.top_p, gc.min_p = 1.0, None
         if (hf_kwargs.get("num_beams") or 1) != 1:
             raise ValueError(f"num_beams={hf_kwargs['num_beams']}: the engine samples or decodes greedily, it has no beam search")
         if isinstance(gc.eos_token_id, (list, tuple)):

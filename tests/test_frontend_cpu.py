@@ -293,3 +293,24 @@ def test_mixed_image_and_video_prompt_keeps_prompt_order(tmp_path, monkeypatch):
     assert len(vis) == 12 + 4 and pos.shape == (3, len(ids))
     with pytest.raises(ValueError, match="not in prompt order"):
         ri.vision_layout(ids, cfg.video_token_id, cfg.image_token_id, grids[::-1], out["second_per_grid_ts"][::-1])
+
+
+def test_image_processor_pixel_range_comes_from_the_checkpoint_directory(tmp_path):
+    """the HF image processor resizes once more under ITS OWN pixel range (preprocessor_config.json beside the weights): read from
+    the model directory, both key styles; an image the element's range lets through is cut down to the processor's"""
+    from PIL import Image
+    assert fe.processor_pixel_range(None) == (3136, 12845056)
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"min_pixels": 3136, "max_pixels": 4704}))
+    assert fe.processor_pixel_range(str(tmp_path)) == (3136, 4704)
+    (tmp_path / "preprocessor_config.json").write_text(json.dumps({"size": {"shortest_edge": 3136, "longest_edge": 6272}}))
+    assert fe.processor_pixel_range(str(tmp_path)) == (3136, 6272)
+    img = Image.fromarray(np.random.default_rng(3).integers(0, 256, size=(112, 112, 3), dtype=np.uint8))
+    ele = {"image": img, "min_pixels": 3136, "max_pixels": 200000}
+    assert fe.read_image(ele).shape == (1, 3, 112, 112)
+    small = fe.read_image(ele, (3136, 4704))
+    assert small.shape == (1, 3, 56, 56)
+    want = np.asarray(img.resize((112, 112)).resize((56, 56), resample=Image.BICUBIC))
+    assert np.array_equal(small[0].permute(1, 2, 0).numpy(), want)
+    cfg = ModelConfig.tiny()
+    pf = fe.ProcessingFrontEnd(cfg, fe.ByteTokenizer(cfg), model_dir=str(tmp_path))
+    assert pf.image_pixels == (3136, 6272)

@@ -152,7 +152,7 @@ def train(argv=None, processing_fn=None, dataset=None):
     if processing_fn is None:
         tok = hfe.load_tokenizer(args.model_id if os.path.isdir(str(args.model_id)) else None, model.cfg)
         log(f"tokeniser: {type(tok).__name__}; video front end on {max(0, args.dataloader_num_workers)} prefetch thread(s)")
-        processing_fn = hfe.ProcessingFrontEnd(model.cfg, tok)
+        processing_fn = hfe.ProcessingFrontEnd(model.cfg, tok, model_dir=args.model_id if os.path.isdir(str(args.model_id)) else None)
     module = rewards.resolve_reward_module(args.reward_module)
     funcs, weights, names = rewards.load_reward_funcs(module, args)
     log(f"reward functions {names} (weights {weights}) from {module}")

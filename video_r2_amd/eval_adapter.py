@@ -53,7 +53,7 @@ class VideoR2EvalModel:
             model = VideoR2Model.from_pretrained(pretrained, device=device)
         self._model = model
         self._tokenizer = tokenizer if tokenizer is not None else load_tokenizer(pretrained, model.cfg)
-        self.front = ProcessingFrontEnd(model.cfg, self._tokenizer, clip_opener)
+        self.front = ProcessingFrontEnd(model.cfg, self._tokenizer, clip_opener, model_dir=pretrained if isinstance(pretrained, str) else None)
         self.open = clip_opener
         self.min_pixels, self.max_pixels, self.max_num_frames, self.fps = int(min_pixels), int(max_pixels), int(max_num_frames), fps
         self.system_prompt = system_prompt
@@ -141,7 +141,7 @@ class VideoR2EvalModel:
                 v.convert("RGB").save(buf, format="JPEG")
                 ele = {"type": "image", "image": "data:image/jpeg;base64," + base64.b64encode(buf.getvalue()).decode("utf-8"),
                        "max_pixels": self.max_pixels, "min_pixels": self.min_pixels}
-                frame = read_image(ele)
+                frame = read_image(ele, self.front.image_pixels)
                 content.append(ele)
                 clips.append(dict(frames_u8=frame, resize_to=None))
                 secs.append(None)                                        # None = still image

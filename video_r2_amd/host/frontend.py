@@ -349,6 +349,20 @@ def read_video(ele, clip=None):
 PROCESSOR_MIN_PIXELS, PROCESSOR_MAX_PIXELS = 56 * 56, 28 * 28 * 16384      # Qwen2.5-VL preprocessor_config.json (min / max_pixels)
 
 
+def processor_pixel_range(model_dir):
+    """(min_pixels, max_pixels) of the checkpoint's image processor: `preprocessor_config.json` beside the weights (keys
+    min_pixels / max_pixels, or size.shortest_edge / size.longest_edge in newer files); the Qwen2.5-VL values without one."""
+    lo, hi = PROCESSOR_MIN_PIXELS, PROCESSOR_MAX_PIXELS
+    path = os.path.join(model_dir, "preprocessor_config.json") if model_dir else None
+    if path and os.path.exists(path):
+        with open(path) as f:
+            pc = json.load(f)
+        size = pc.get("size") or {}
+        lo = int(pc.get("min_pixels") or size.get("shortest_edge") or lo)
+        hi = int(pc.get("max_pixels") or size.get("longest_edge") or hi)
+    return lo, hi
+
+
 def open_image(src):
     """PIL image from what an image element may hold (vision_process.py:374-400): a PIL image, a path, file://, http(s)://
     or a data:image;base64 URI."""
@@ -492,8 +506,9 @@ def load_tokenizer(model_dir, cfg):
 class ProcessingFrontEnd:
     """processing_fn(example) for QwenGRPOTrainer: dataset example -> prompt ids + uint8 clips + decode()."""
 
-    def __init__(self, cfg, tokenizer, clip_opener=open_clip):
+    def __init__(self, cfg, tokenizer, clip_opener=open_clip, model_dir=None):
         self.cfg, self.tok, self.open = cfg, tokenizer, clip_opener
+        self.image_pixels = processor_pixel_range(model_dir)      # the HF image processor's own resize range (second image stage)
 
     def video_tokens(self, n_frames, h, w):
         v = self.cfg.vision
@@ -508,7 +523,7 @@ class ProcessingFrontEnd:
                 continue
             for c in m["content"]:
                 if c.get("type") == "image" or "image" in c or "image_url" in c:
-                    frame = read_image(c)                    # [1,3,H',W'], already at its final size (PIL, as the reference)
+                    frame = read_image(c, self.image_pixels)  # [1,3,H',W'], already at its final size (PIL, as the reference)
                     videos.append((frame.pin_memory() if torch.cuda.is_available() else frame, None))
                     secs.append(None)                        # None = still image (HF has second_per_grid_ts for videos only)
                     counts.append(self.video_tokens(1, int(frame.shape[2]), int(frame.shape[3])))

@@ -78,3 +78,43 @@ def test_generate_until_matches_direct_decode_and_keeps_order(tmp_path):
     s1 = ev.generate_until([Req("q", {"temperature": 0.8, "max_new_tokens": 6, "seed": 5}, vis, 0, "videomme", "test")])
     s2 = ev.generate_until([Req("q", {"temperature": 0.8, "max_new_tokens": 6, "seed": 5}, vis, 0, "videomme", "test")])
     assert s1 == s2
+
+
+def test_generate_until_takes_pil_images_like_the_harness(tmp_path):
+    """a document whose visuals are PIL images (the harness sends them as RGB JPEG data URIs, qwen2_5_vl.py:239-245): the answer is
+    the greedy decode of [system, user[image, image, text]] with the JPEG round trip's pixels under fetch_image's resize"""
+    import base64
+    import io
+    from PIL import Image
+    from video_r2_amd.eval_adapter import VideoR2EvalModel
+    from video_r2_amd.host.frontend import IMAGE_PAD, ByteTokenizer, read_image, render_chat
+    from video_r2_amd.model import VideoR2Model
+    ocfg = om.cfg_tiny(2)
+    cfg = to_engine_cfg(ocfg)
+    m = VideoR2Model.from_state_dict(cfg, om.make_weights(ocfg, seed=19), device="cuda:0")
+    tok = ByteTokenizer(cfg)
+    rng = np.random.default_rng(5)
+    imgs = [Image.fromarray(rng.integers(0, 256, size=(60, 90, 3), dtype=np.uint8)),
+            Image.fromarray(rng.integers(0, 256, size=(64, 64, 4), dtype=np.uint8), mode="RGBA")]
+    docs = {"mmbench": {"test": [{"imgs": imgs, "q": "Which one is brighter?"}]}}
+    ev = VideoR2EvalModel(model=m, tokenizer=tok, task_dict=docs, min_pixels=3136, max_pixels=4704)
+    out = ev.generate_until([Req("<image><image>Which one is brighter?", {"max_new_tokens": 7, "temperature": 0}, lambda d: d["imgs"], 0, "mmbench", "test")])
+    assert len(out) == 1 and isinstance(out[0], str)
+    # the same request by hand
+    eles, clips, counts = [], [], []
+    for im in imgs:
+        buf = io.BytesIO()
+        im.convert("RGB").save(buf, format="JPEG")
+        ele = {"type": "image", "image": "data:image/jpeg;base64," + base64.b64encode(buf.getvalue()).decode("utf-8"), "max_pixels": 4704, "min_pixels": 3136}
+        fr = read_image(ele)
+        eles.append(ele); clips.append(dict(frames_u8=fr, resize_to=None)); counts.append(ev.front.video_tokens(1, int(fr.shape[2]), int(fr.shape[3])))
+    (emb, plan), = m.engine.encode_videos(clips, per_prompt=[2])
+    text = render_chat([{"role": "system", "content": "You are a helpful assistant."},
+                        {"role": "user", "content": eles + [{"type": "text", "text": "Which one is brighter?"}]}])
+    a, b, c = text.split(IMAGE_PAD)
+    ids = np.asarray(tok.encode(a) + [cfg.image_token_id] * counts[0] + tok.encode(b) + [cfg.image_token_id] * counts[1] + tok.encode(c), dtype=np.int64)
+    st = m.engine.prefill(m.text, ids, emb, plan, [None, None])
+    toks, _ = m.engine.decode(m.text, st, 1, 7, temperature=1.0, top_k=1, seed=0, eos_token_id=cfg.eos_token_id)
+    row = toks[0].cpu().numpy()
+    stop = np.flatnonzero(row == cfg.eos_token_id)
+    assert out[0] == tok.decode((row[:stop[0]] if stop.size else row).tolist(), skip_special_tokens=True)

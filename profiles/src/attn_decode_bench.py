@@ -19,7 +19,7 @@ vs = [torch.randn(G * C, nKV * hd, device=dev, generator=g).to(torch.bfloat16) f
 q = torch.randn(G, nH * hd, device=dev, generator=g).to(torch.bfloat16)
 po = torch.zeros(G * nH * (npc + nsc), hd, device=dev); pml = torch.zeros(G * nH * (npc + nsc), 2, device=dev)
 out = torch.zeros(G, nH * hd, dtype=torch.bfloat16, device=dev)
-plen = torch.full((P,), S_, dtype=torch.int32, device=dev)
+plen = torch.full((P,), int(os.environ.get('VR2_PLEN', S_)), dtype=torch.int32, device=dev)   # live prompt keys (<= S_)
 for step in [int(a) for a in sys.argv[1:]] or [15, 255, 511, 1023]:
     stp = torch.tensor([step], dtype=torch.int32, device=dev)
 

@@ -496,6 +496,33 @@ def test_sample_two_stage_equals_single_pass(dev):
     assert (torch.gather(logits.cpu(), 1, a.cpu().long()[:, None])[:, 0] >= kth).all()
 
 
+def test_sample_two_stage_top_values_crowded_into_few_threads(dev):
+    """the candidate kernel bounds a slice's k-th largest key by the k-th largest of its 256 THREAD maxima and ranks the keys above
+    that bound in a short list; when the slice's large values all sit in the registers of a few threads the bound is low, the list
+    overflows and the kernel must fall back to the radix select over all keys -- same token as the single-pass kernel either way"""
+    V, G, NSLICE = 152064, 4, 32
+    L = V // NSLICE
+    g = torch.Generator().manual_seed(21)
+    logits = torch.randn(G, V, generator=g)
+    i = torch.arange(L)
+    crowded = (i % 256) < 41                                   # thread tid holds slice elements tid + 256 j: 41 threads x 19 = 779 keys
+    logits[0, :L][crowded] += 30.0                             # row 0, slice 0: 779 keys far above the rest (> the 768-entry list)
+    logits[1, 5 * L:6 * L][crowded] += 30.0                    # row 1, slice 5
+    logits[2, :L][(i % 256) < 3] += 30.0                       # row 2: 57 large keys in 3 threads (the list holds them: no fallback)
+    logits = logits.to(dev)
+    ws = torch.zeros(int(lib.load().vr2_sample_ws_bytes(G)) // 4, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = torch.zeros(G, dtype=torch.int32, device=dev); b = torch.zeros(G, dtype=torch.int32, device=dev)
+    for it in range(16):
+        step.fill_(it)
+        lib.call("vr2_sample_topk", logits, V, G, V, 0.9, 50, 7, None, step, None, -1, 0, a, None, 0, None, S())
+        lib.call("vr2_sample_topk", logits, V, G, V, 0.9, 50, 7, None, step, None, -1, 0, b, None, 0, ws, S())
+        assert torch.equal(a, b), (it, a.tolist(), b.tolist())
+    kth = torch.topk(logits.cpu(), 50)[0][:, -1]
+    assert (torch.gather(logits.cpu(), 1, b.cpu().long()[:, None])[:, 0] >= kth).all()
+    assert int(b[0]) < L and (int(b[0]) % 256) < 41 and 5 * L <= int(b[1]) < 6 * L
+
+
 def test_lse_gather(dev):
     R, V = 33, 2048
     g = torch.Generator().manual_seed(4)

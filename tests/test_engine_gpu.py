@@ -719,3 +719,27 @@ def test_vision_items_out_of_order_or_missing_are_refused():
         eng.prefill(eng.text, ids2, emb, plan, [None, 1.0])
     with pytest.raises(ValueError, match="do not match"):
         eng.prefill(eng.text, ids[:-3], emb, plan, [None, 1.0])
+
+
+def test_workspace_allocation_retries_after_a_cache_flush_and_explains_a_real_oom(monkeypatch):
+    """Engine.buf: an out-of-memory on a growing workspace is retried once after dropping the buffer it replaces and flushing the
+    caching allocator's free blocks; a second failure is re-raised with the buffer's name, its size and what to lower"""
+    ocfg = om.cfg_tiny(2)
+    eng, w, cfg = make_engine(ocfg, 5)
+    real = torch.empty
+    fails = {"n": 1}
+
+    def flaky(*a, **k):
+        if fails["n"] > 0 and k.get("device") is not None:
+            fails["n"] -= 1
+            raise torch.OutOfMemoryError("injected")
+        return real(*a, **k)
+
+    monkeypatch.setattr(torch, "empty", flaky)
+    b = eng.buf("t.oom_probe", (300, 64), torch.float32)
+    assert b.shape == (300, 64) and fails["n"] == 0                 # first attempt failed, the retry went through
+    fails["n"] = 2
+    with pytest.raises(torch.OutOfMemoryError, match="t.oom_probe2.*does not fit.*max_completion_length"):
+        eng.buf("t.oom_probe2", (300, 64), torch.float32)
+    monkeypatch.setattr(torch, "empty", real)
+    assert eng.buf("t.oom_probe2", (10, 64), torch.float32).shape == (10, 64)

@@ -115,8 +115,27 @@ class Engine:
         if b is None or b.shape[gd] < need:
             cap = need if need <= 256 else (need + need // 8 + 127) // 128 * 128       # 12.5 % headroom on long dimensions
             full = shape[:gd] + (cap,) + shape[gd + 1:]
+            make = torch.zeros if zero else torch.empty
             with torch.cuda.stream(self.stream):
-                b = torch.zeros(full, dtype=dtype, device=self.device) if zero else torch.empty(full, dtype=dtype, device=self.device)
+                try:
+                    b = make(full, dtype=dtype, device=self.device)
+                except torch.OutOfMemoryError:
+                    # the buffer this one replaces and the caching allocator's free blocks may be all that is in the way
+                    self._ws.pop(key, None)
+                    b = None
+                    self.stream.synchronize()
+                    torch.cuda.empty_cache()
+                    try:
+                        b = make(full, dtype=dtype, device=self.device)
+                    except torch.OutOfMemoryError as e:
+                        free, total = torch.cuda.mem_get_info(self.device)
+                        gib = float(np.prod(full)) * torch.empty((), dtype=dtype).element_size() / 2 ** 30
+                        raise torch.OutOfMemoryError(
+                            f"workspace '{name}' {full} {dtype} ({gib:.1f} GiB) does not fit: {free / 2 ** 30:.1f} GiB free of "
+                            f"{total / 2 ** 30:.0f} GiB.  The saved activations of a training pass grow with (prompt rows + "
+                            "num_generations x completion rows) x layers; prefix caches and decode buffers with the prompt groups "
+                            "decoded together: lower --max_completion_length / --num_generations, the frame budget (FPS_MAX_FRAMES, "
+                            "--video_max_pixels) or --per_device_train_batch_size.") from e
             self._ws[key] = b
             self._ws_epoch += 1                                                         # captured graphs hold old addresses
         return b.narrow(gd, 0, need)

@@ -266,7 +266,6 @@ def main():
     n_prompts = (a.steps + a.warmup + 1) * P + 2            # + one instrumented step for the phase split + 2 recipe-shaped steps
     prompts = [synth_prompt(cfg, a.frames, rank * 1000 + i, device) for i in range(n_prompts)]
     slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="pol")
-    ref_slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="ref")
     torch.cuda.synchronize()
 
     def step(i, rec=None, mine=None, lens=None):
@@ -291,17 +290,16 @@ def main():
         comp_all = toks_all.cpu().numpy()                              # the rewards are host functions of the completions: ONE copy
         rew_all = torch.from_numpy(stub_rewards(comp_all)).to(device)  # per step, no host sync inside the loop over the groups
         losses = []
-        mark(None)
-        ref_states = eng.prefill_batch(ref, [(ids, enc[p_][0], enc[p_][1], [1.0]) for p_, (_, _, ids) in enumerate(mine)], ref_slots[:Pn], tag="ref")
-        mark("ref_prefill+ref_score")
         for p_, (px, grid, ids) in enumerate(mine):
             emb, plan = enc[p_]
             toks = toks_all[p_ * G:(p_ + 1) * G]
             mark(None)
             ln = None if lens is None else np.minimum(lens[p_ * G:(p_ + 1) * G], Cd)
-            lp_ref = eng.score(ref, ref_states[p_], toks, 0.9, tag="ref", lens=ln)
+            # reference log-probs over the unified [prompt | completions] row space: the row space and launches of the policy's
+            # training forward below, so identical weights give identical bits (Engine.score_unified)
+            lp_ref = eng.score_unified(ref, ids, emb, plan, [1.0], toks, 0.9, tag="ref", lens=ln)
             mark("ref_prefill+ref_score")
-            lp = (eng.score(pol, states[p_], toks, 0.9, tag="pol", lens=ln) if upd is None
+            lp = (eng.score_unified(pol, ids, emb, plan, [1.0], toks, 0.9, tag="ref", lens=ln, allow_fp8=False) if upd is None
                   else upd.forward(ids, emb, plan, [1.0], toks, 0.9, lens=ln))
             mark("policy_forward")
             with torch.cuda.stream(eng.stream):

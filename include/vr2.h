@@ -45,6 +45,13 @@ int vr2_tune_set(int key, int value);
  * train/src/trainer/grpo_trainer.py:725-727 and :783-786.  K % 64 == 0 (pad operands), N % 4 == 0. */
 int vr2_gemm_bf16(const void* A_bf16, int64_t lda, const void* W_packed_bf16, const void* bias_f32, void* C, int64_t ldc,
                   int64_t M, int64_t N, int64_t K, int epilogue, void* stream);
+/* fp32 scratch for the GEMMs' split launches: the <= 128 tail rows of a 256-row tiling with few output tiles (N = 3584 at
+ * T = 9280: the o / down projections and their dgrads) run as k-parts that each store a partial tile here and are summed in part
+ * order -- deterministic, unlike atomic adds, so two passes over the same weights give the same bits
+ * (grpo_trainer.py:723-741 called for the policy :1094 and the reference :826).  8 MiB covers every shape; the caller owns the
+ * memory and runs the GEMMs that use it on one stream.  Without a workspace those tail rows run as full-K tiles (slower, same
+ * determinism).  ptr = NULL, bytes = 0 unregisters. */
+int vr2_set_gemm_workspace(void* ptr, int64_t bytes);
 
 /* Decode-step weight streaming for M <= 64 rows: out[s][m][n] = sum over K-slice s of x[m][k] W[n][k] (fp32 partial
  * slabs, summed by the consumer).  Replaces the 1-token forward of HF generate, generation/utils.py:2876-2937 (K11

@@ -164,6 +164,45 @@ def _bf16(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def _rounders(emulate_bf16=False, rounding=None):
+    """(rd, ro) for the three precisions this restatement runs in.
+
+    rounding = None / "fp32": the checker proper, no rounding anywhere (rd = ro = identity).
+    rounding = "bf16" (= emulate_bf16=True): EVERY op's output rounded to bfloat16 -- the precision the reference runs the model
+      in (torch_dtype=bfloat16, bf16 residual stream and log-softmax): rd = ro = round.
+    rounding = "operands": the HIP engine's own rounding points and nothing else -- the INPUTS of every matrix
+      multiply are bfloat16 (normed activations, q / k / v after the rotation, the unnormalised softmax weights, the attention
+      output, the SwiGLU / GELU output, the pixel patches), while accumulation, biases, residual stream, norms, softmax sums,
+      rotary arithmetic and the log-softmax stay fp32: rd = identity, ro = round.  Comparing the engine with THIS mode isolates
+      everything that is not an operand rounding (tile tails, layouts, masks, k order) at widths and depths where the operand
+      roundings alone exceed the 1e-3 bar against fp32."""
+    if rounding is None:
+        rounding = "bf16" if emulate_bf16 else "fp32"
+    if rounding not in ("fp32", "bf16", "operands"):
+        raise ValueError(f"rounding must be fp32 | bf16 | operands, got {rounding!r}")
+    if rounding == "bf16":
+        return _bf16, _bf16
+    if rounding == "operands":
+        return _ident, _bf16
+    return _ident, _ident
+
+
+def _attend(q, k, v, scale, bias, rd, ro):
+    """softmax(q k^T * scale + bias) v over the last two dims.  With operand rounding the matrix unit sees bf16 copies of the
+    UNNORMALISED weights p = exp(s - max) and the division by sum(p) (fp32, of the unrounded p) comes after P V, as a
+    flash-style kernel does it."""
+    s = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    if ro is _ident or rd is not _ident:
+        att = rd(torch.nan_to_num(s.softmax(-1)))     # nan: fully-masked (padding) query rows
+        return rd(att @ v)
+    m = s.amax(-1, keepdim=True)
+    p = torch.exp(s - torch.where(torch.isfinite(m), m, torch.zeros_like(m)))
+    den = p.sum(-1, keepdim=True)
+    return torch.nan_to_num((ro(p) @ v) / den)
+
+
 def fp8_qdq_rows(x):
     """Per-row e4m3 quantise-dequantise of bf16-rounded activations: what vr2_quant_rows_fp8 + the a8w8 GEMVs see (BASELINE
     config 5 with fp8 activations): scale = amax / 448 over the last dim, round to nearest even, x ~= q * scale."""
@@ -187,17 +226,17 @@ def rotate_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
-def vision_forward(w, cfg: Cfg, pixel_values, grid_thw, return_hidden=False, emulate_bf16=False):
+def vision_forward(w, cfg: Cfg, pixel_values, grid_thw, return_hidden=False, emulate_bf16=False, rounding=None):
     """HF:408-471 (Qwen2_5_VisionTransformerPretrainedModel.forward).  pixel_values [P, C*tp*ps*ps].
     emulate_bf16: round every op's output to bfloat16 (the precision the reference actually runs the model in,
     /root/reference/train/src/train/train_grpo.py compute_dtype) -- used by tests to measure the reference's OWN deviation
-    from this fp32 restatement at depths where bf16 noise exceeds the 1e-3 tolerance."""
-    rd = _bf16 if emulate_bf16 else _ident
+    from this fp32 restatement at depths where bf16 noise exceeds the 1e-3 tolerance.  rounding: see _rounders."""
+    rd, ro = _rounders(emulate_bf16, rounding)
     v = cfg.vision
     grid = [tuple(int(a) for a in g) for g in np.asarray(grid_thw).reshape(-1, 3)]
     unit = v.spatial_merge_size ** 2
     hd = v.hidden_size // v.num_heads
-    x = rd(rd(pixel_values.float()) @ w["visual.patch_embed.proj.weight"].reshape(v.hidden_size, -1).t())   # HF:115-122
+    x = rd(ro(pixel_values.float()) @ w["visual.patch_embed.proj.weight"].reshape(v.hidden_size, -1).t())   # HF:115-122
     P = x.shape[0]
     win_idx, cu_win = vi.vision_window_index(grid, v.spatial_merge_size, v.window_size, v.patch_size)
     cu_full = vi.vision_cu_seqlens(grid)
@@ -214,24 +253,23 @@ def vision_forward(w, cfg: Cfg, pixel_values, grid_thw, return_hidden=False, emu
     for li in range(v.depth):
         p = f"visual.blocks.{li}."
         cu = cu_full if li in v.fullatt_block_indexes else cu_win
-        h = rms_norm(x, w[p + "norm1.weight"], 1e-6, rd)
+        h = ro(rms_norm(x, w[p + "norm1.weight"], 1e-6, rd))
         qkv = rd(h @ w[p + "attn.qkv.weight"].t() + w[p + "attn.qkv.bias"])
         q, k, vv = qkv.reshape(P, 3, v.num_heads, hd).permute(1, 0, 2, 3).unbind(0)                     # [P,H,hd]
-        q = rd(q * cos + rotate_half(q) * sin)                                                          # HF:160-171 (fp32 inside)
-        k = rd(k * cos + rotate_half(k) * sin)
+        q = ro(rd(q * cos + rotate_half(q) * sin))                                                      # HF:160-171 (fp32 inside)
+        k = ro(rd(k * cos + rotate_half(k) * sin))
+        vv = ro(vv)
         o = torch.empty_like(q)
         for s in range(len(cu) - 1):                                                                    # HF:266-287
             a, b = int(cu[s]), int(cu[s + 1])
-            att = torch.einsum("qhd,khd->hqk", q[a:b], k[a:b]) * scale
-            att = rd(att.softmax(-1))
-            o[a:b] = rd(torch.einsum("hqk,khd->qhd", att, vv[a:b]))
-        x = rd(x + rd(o.reshape(P, -1) @ w[p + "attn.proj.weight"].t() + w[p + "attn.proj.bias"]))
-        h = rms_norm(x, w[p + "norm2.weight"], 1e-6, rd)
+            o[a:b] = _attend(q[a:b].transpose(0, 1), k[a:b].transpose(0, 1), vv[a:b].transpose(0, 1), scale, None, rd, ro).transpose(0, 1)
+        x = rd(x + rd(ro(o.reshape(P, -1)) @ w[p + "attn.proj.weight"].t() + w[p + "attn.proj.bias"]))
+        h = ro(rms_norm(x, w[p + "norm2.weight"], 1e-6, rd))
         g = rd(F.silu(rd(h @ w[p + "mlp.gate_proj.weight"].t() + w[p + "mlp.gate_proj.bias"])))
         u = rd(h @ w[p + "mlp.up_proj.weight"].t() + w[p + "mlp.up_proj.bias"])
-        x = rd(x + rd(rd(g * u) @ w[p + "mlp.down_proj.weight"].t() + w[p + "mlp.down_proj.bias"]))
-    m = rms_norm(x, w["visual.merger.ln_q.weight"], 1e-6, rd).reshape(P // unit, -1)                    # HF:147-150
-    m = rd(F.gelu(rd(m @ w["visual.merger.mlp.0.weight"].t() + w["visual.merger.mlp.0.bias"])))
+        x = rd(x + rd(ro(rd(g * u)) @ w[p + "mlp.down_proj.weight"].t() + w[p + "mlp.down_proj.bias"]))
+    m = ro(rms_norm(x, w["visual.merger.ln_q.weight"], 1e-6, rd)).reshape(P // unit, -1)                # HF:147-150
+    m = ro(rd(F.gelu(rd(m @ w["visual.merger.mlp.0.weight"].t() + w["visual.merger.mlp.0.bias"]))))
     m = rd(m @ w["visual.merger.mlp.2.weight"].t() + w["visual.merger.mlp.2.bias"])
     m = m[torch.argsort(win_idx_t)]                                                                     # HF:464-466
     return (m, x) if return_hidden else m
@@ -251,11 +289,12 @@ def mrope_cos_sin(cfg: Cfg, position_ids):
     return cos, sin
 
 
-def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv_cache=None, emulate_bf16=False, act_quant=None):
+def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv_cache=None, emulate_bf16=False, act_quant=None,
+               rounding=None):
     """HF:790-872 + decoder layers :641-757.  inputs_embeds [B,S,H]; position_ids [3,B,S];
     attention_mask [B, S_total] over cached+new keys (1 = attend).  kv_cache: list of (k,v) [B,Hkv,T,hd]
-    (updated in place when given).  Returns final-normed hidden [B,S,H]."""
-    rd = _bf16 if emulate_bf16 else _ident
+    (updated in place when given).  Returns final-normed hidden [B,S,H].  rounding: see _rounders."""
+    rd, ro = _rounders(emulate_bf16, rounding)
     aq = act_quant if act_quant is not None else _ident       # applied to the input of every projection (config 5, fp8 activations)
     t = cfg.text
     B, S, H = inputs_embeds.shape
@@ -274,12 +313,13 @@ def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv
     x = rd(inputs_embeds.float())
     for li in range(t.num_hidden_layers):
         p = f"model.layers.{li}."
-        h = aq(rms_norm(x, w[p + "input_layernorm.weight"], t.rms_norm_eps, rd))
+        h = aq(ro(rms_norm(x, w[p + "input_layernorm.weight"], t.rms_norm_eps, rd)))
         q = rd(h @ w[p + "self_attn.q_proj.weight"].t() + w[p + "self_attn.q_proj.bias"]).view(B, S, nh, hd).transpose(1, 2)
         k = rd(h @ w[p + "self_attn.k_proj.weight"].t() + w[p + "self_attn.k_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
         v = rd(h @ w[p + "self_attn.v_proj.weight"].t() + w[p + "self_attn.v_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
-        q = rd(rd(q * cos) + rd(rotate_half(q) * sin))
-        k = rd(rd(k * cos) + rd(rotate_half(k) * sin))
+        q = ro(rd(rd(q * cos) + rd(rotate_half(q) * sin)))
+        k = ro(rd(rd(k * cos) + rd(rotate_half(k) * sin)))
+        v = ro(v)
         if kv_cache is not None:
             if kv_cache[li] is not None:
                 k = torch.cat([kv_cache[li][0], k], dim=2)
@@ -287,15 +327,12 @@ def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv
             kv_cache[li] = (k, v)
         kr = k.repeat_interleave(nh // nkv, dim=1)
         vr = v.repeat_interleave(nh // nkv, dim=1)
-        att = (q @ kr.transpose(2, 3)) * (hd ** -0.5) + bias
-        att = att.softmax(-1)
-        att = rd(torch.nan_to_num(att))  # fully-masked (padding) query rows
-        o = rd(att @ vr).transpose(1, 2).reshape(B, S, nh * hd)
-        x = rd(x + rd(aq(o) @ w[p + "self_attn.o_proj.weight"].t()))
-        h = aq(rms_norm(x, w[p + "post_attention_layernorm.weight"], t.rms_norm_eps, rd))
+        o = _attend(q, kr, vr, hd ** -0.5, bias, rd, ro).transpose(1, 2).reshape(B, S, nh * hd)
+        x = rd(x + rd(aq(ro(o)) @ w[p + "self_attn.o_proj.weight"].t()))
+        h = aq(ro(rms_norm(x, w[p + "post_attention_layernorm.weight"], t.rms_norm_eps, rd)))
         g = rd(rd(F.silu(rd(h @ w[p + "mlp.gate_proj.weight"].t()))) * rd(h @ w[p + "mlp.up_proj.weight"].t()))
-        x = rd(x + rd(aq(g) @ w[p + "mlp.down_proj.weight"].t()))
-    return rms_norm(x, w["model.norm.weight"], t.rms_norm_eps, rd)
+        x = rd(x + rd(aq(ro(g)) @ w[p + "mlp.down_proj.weight"].t()))
+    return ro(rms_norm(x, w["model.norm.weight"], t.rms_norm_eps, rd))
 
 
 def lm_head_weight(w, cfg):
@@ -323,24 +360,24 @@ def build_inputs_embeds(w, cfg: Cfg, input_ids, video_embeds, image_embeds=None)
 
 
 def forward_logits(w, cfg: Cfg, input_ids, attention_mask, pixel_values_videos, video_grid_thw, second_per_grid_ts,
-                   video_embeds=None, emulate_bf16=False, pixel_values=None, image_grid_thw=None, image_embeds=None):
+                   video_embeds=None, emulate_bf16=False, pixel_values=None, image_grid_thw=None, image_embeds=None, rounding=None):
     """Full forward -> logits [B,S,V] fp32 (HF:1308-1402 without the loss).  Still images (pixel_values, image_grid_thw: the
     `images=` half of the reference's processor call, grpo_trainer.py:759-767) go through the same vision tower in a pass of
     their own, as HF's get_image_features does."""
     ids = torch.as_tensor(input_ids)
     if video_embeds is None and pixel_values_videos is not None:
-        video_embeds = vision_forward(w, cfg, pixel_values_videos, video_grid_thw, emulate_bf16=emulate_bf16)
+        video_embeds = vision_forward(w, cfg, pixel_values_videos, video_grid_thw, emulate_bf16=emulate_bf16, rounding=rounding)
     if image_embeds is None and pixel_values is not None:
-        image_embeds = vision_forward(w, cfg, pixel_values, image_grid_thw, emulate_bf16=emulate_bf16)
+        image_embeds = vision_forward(w, cfg, pixel_values, image_grid_thw, emulate_bf16=emulate_bf16, rounding=rounding)
     emb = build_inputs_embeds(w, cfg, ids, video_embeds, image_embeds)
     am = None if attention_mask is None else np.asarray(attention_mask)
     pos, _ = vi.rope_index(ids.numpy(), am, video_grid_thw, second_per_grid_ts, video_token_id=cfg.video_token_id,
                            image_token_id=cfg.image_token_id, image_grid_thw=image_grid_thw,
                            merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
     h = lm_forward(w, cfg, emb, torch.from_numpy(pos), None if attention_mask is None else torch.as_tensor(attention_mask),
-                   emulate_bf16=emulate_bf16)
+                   emulate_bf16=emulate_bf16, rounding=rounding)
     logits = h @ lm_head_weight(w, cfg).t()
-    return _bf16(logits) if emulate_bf16 else logits
+    return _rounders(emulate_bf16, rounding)[0](logits)
 
 
 def selective_log_softmax(logits, index):
@@ -352,9 +389,10 @@ def selective_log_softmax(logits, index):
 def per_token_logps(w, cfg, input_ids, attention_mask, logits_to_keep, temperature, **mm):
     """/root/reference/train/src/trainer/grpo_trainer.py:723-741."""
     ids = torch.as_tensor(input_ids)
-    emu = bool(mm.get("emulate_bf16", False))
+    rounding = mm.get("rounding") or ("bf16" if mm.get("emulate_bf16") else "fp32")
+    emu = rounding == "bf16"
     logits = forward_logits(w, cfg, ids, attention_mask, mm.get("pixel_values_videos"), mm.get("video_grid_thw"),
-                            mm.get("second_per_grid_ts"), video_embeds=mm.get("video_embeds"), emulate_bf16=emu,
+                            mm.get("second_per_grid_ts"), video_embeds=mm.get("video_embeds"), rounding=rounding,
                             pixel_values=mm.get("pixel_values"), image_grid_thw=mm.get("image_grid_thw"),
                             image_embeds=mm.get("image_embeds"))
     logits = logits[:, :-1, :]

@@ -278,6 +278,30 @@ def test_workspaces_are_reused_across_prompt_lengths():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])                   # and re-use does not change results
 
 
+def test_packed_scoring_with_different_row_counts_keeps_workspaces_and_graphs():
+    """packed scoring (lens=) runs sum(lens) rows, a different count for almost every group, and prefill(all_logits=) runs one
+    count per prompt length: neither may allocate a workspace per row count (each allocation also bumps _ws_epoch, which drops
+    the captured decode graphs)"""
+    ocfg = om.cfg_tiny(2)
+    eng, w, cfg = make_engine(ocfg, 36)
+    prompt = np.arange(100, 140)
+    st = eng.prefill(eng.text, prompt, None, None, None)
+    G, C = 4, 300                                              # 1200 dense rows: a full 1024-row logits chunk plus a tail
+    toks, _ = eng.decode(eng.text, st, G, C, seed=3)
+    dense = eng.score(eng.text, st, toks, 0.9)
+    lg = torch.empty((len(prompt), cfg.text.vocab_size), dtype=torch.float32, device=eng.device)
+    eng.prefill(eng.text, prompt, None, None, None, tag="fwd", all_logits=lg)
+    eng.sync()
+    n_bufs, epoch, n_graphs = len(eng._ws), eng._ws_epoch, len(eng._graphs)
+    for lens in ([300, 299, 12, 150], [7, 300, 300, 222], [1, 1, 1, 1], [300, 300, 300, 299]):
+        lp = eng.score(eng.text, st, toks, 0.9, lens=np.asarray(lens))
+        for g_, n in enumerate(lens):
+            assert torch.equal(lp[g_, :n], dense[g_, :n]) and not lp[g_, n:].any()
+        eng.prefill(eng.text, prompt[:len(prompt) - lens[2] % 9], None, None, None, tag="fwd", all_logits=lg)
+    eng.sync()
+    assert (len(eng._ws), eng._ws_epoch, len(eng._graphs)) == (n_bufs, epoch, n_graphs)
+
+
 def test_device_patchify_is_bit_identical_to_the_host_processor():
     """vr2_patchify_u8 (uint8 frames -> normalised, patchified, window-gathered bf16 GEMM rows on the device) against the host
     path (processor.normalize_frames + patchify -> H2D -> cast/gather): same bits in the GEMM input, same video tokens; odd

@@ -72,13 +72,66 @@ def test_srt_parsing_and_cue_lookup(tmp_path):
                    "00:00:05,000 --> 00:00:06,000\nno index line\n\n3\n00:00:03,000 --> 00:00:04,000\n\n")
     cues = fe.parse_srt(str(srt))
     assert cues == [(1.0, 2.5, ["hello there", "second line"]), (5.0, 6.0, ["no index line"])]   # sorted, tags stripped, empty cue dropped
-    idx = fe.SubtitleIndex(cues)
-    assert idx.get(0.5) == (None, 0)
-    assert idx.get(0.96) == ("hello there\nsecond line", 0)                        # 50 ms tolerance before the first cue
-    assert idx.get(2.54, 0) == ("hello there\nsecond line", 0)
-    assert idx.get(3.0, 0) == (None, 0)
-    assert idx.get(5.5, 0) == ("no index line", 1)
-    assert fe.SubtitleIndex([]).get(1.0, 3) == (None, 3)
+    trk = fe.SubtitleTrack(cues)
+    assert trk.at(0.5) is None
+    assert trk.at(0.94) is None and trk.at(0.96) == "hello there\nsecond line"    # 50 ms tolerance before the first cue ...
+    assert trk.at(2.54) == "hello there\nsecond line" and trk.at(2.56) is None     # ... and behind its end
+    assert trk.at(3.0) is None
+    assert trk.at(5.5) == "no index line"
+    # a clip's frame times in one call; -1 = nothing on screen
+    assert trk.lookup([0.5, 0.96, 2.0, 3.0, 4.96, 6.04, 6.06]).tolist() == [-1, 0, 0, -1, 1, 1, -1]
+    assert fe.SubtitleTrack([]).texts([1.0, 2.0]) == [None, None]
+
+
+def _reference_cue(cues, times, tol=0.05):
+    """The reference's lookup as a plain scan (vision_process.py:189-212 for non-decreasing times): the last cue with
+    start <= t + tol is the candidate; shown while t < end + tol; a candidate that starts ahead of t hands over to its predecessor."""
+    out = []
+    for t in times:
+        started = [k for k, c in enumerate(cues) if c[0] <= t + tol]
+        pick = -1
+        if started:
+            i = started[-1]
+            s, e = cues[i][0], cues[i][1]
+            if s - tol <= t < e + tol:
+                pick = i
+            elif t < s and i > 0 and cues[i - 1][0] - tol <= t < cues[i - 1][1] + tol:
+                pick = i - 1
+            elif t < s and i == 0 and cues[0][0] - tol <= t < cues[0][1] + tol:
+                pick = 0
+        out.append(pick)
+    return out
+
+
+def test_cue_lookup_edge_cases_follow_the_reference_rule():
+    # overlapping cues: the later start wins; once it has ended the earlier, still running cue is NOT shown again
+    over = [(1.0, 10.0, ["long"]), (2.0, 3.0, ["short"])]
+    trk = fe.SubtitleTrack(over)
+    assert trk.texts([1.5, 1.96, 2.5, 3.04, 3.2, 9.0]) == ["long", "short", "short", "short", None, None]
+    # t just before the first cue, tolerance on both ends, equal starts (file order kept: the later entry is the candidate)
+    cues = [(1.0, 2.0, ["a"]), (2.0, 2.5, ["b"]), (2.0, 4.0, ["c"]), (7.0, 6.0, ["malformed: ends before it starts"]), (8.0, 9.0, ["d"])]
+    times = np.round(np.arange(0.0, 10.0, 0.01), 2)
+    assert fe.SubtitleTrack(cues).lookup(times).tolist() == _reference_cue(cues, times)
+    rng = np.random.default_rng(3)
+    for _ in range(20):                                                              # random tracks, sorted query times
+        st = np.sort(rng.uniform(0, 50, size=12))
+        cues = [(float(a), float(a + rng.uniform(-0.5, 6.0)), ["x"]) for a in st]
+        times = np.sort(rng.uniform(-1, 60, size=400))
+        assert fe.SubtitleTrack(cues).lookup(times).tolist() == _reference_cue(cues, times)
+
+
+def test_word_wrap_keeps_breaks_and_never_splits_words():
+    from PIL import Image, ImageDraw
+    draw, font = ImageDraw.Draw(Image.new("RGB", (8, 8))), fe._font(16)
+    width = lambda s: fe._text_size(draw, font, s)[0]
+    text = "alpha beta gamma delta epsilon\n\nzeta " + "x" * 60 + " eta"
+    lines = fe.wrap_words(draw, font, text, 120)
+    assert " ".join(lines).split() == text.split() and "" in lines                  # all words, in order; the empty paragraph stays
+    assert all(width(ln) <= 120 or " " not in ln for ln in lines)                    # only a single over-long word may overflow
+    for a, b in zip(lines, lines[1:]):                                               # greedy: the next line's first word did not fit
+        if a and b and a.split()[-1] + " " + b.split()[0] in text:
+            assert width(a + " " + b.split()[0]) > 120
+    assert fe.wrap_words(draw, font, "", 50) == [""]
 
 
 def test_overlays_touch_only_their_corner_and_are_deterministic():

@@ -133,3 +133,40 @@ def test_7b_cross_path_properties(frames, G):
     print("7B config 5, prefill + scoring on fp8 operands: logp rel err vs the bf16 pass mean %.2e p95 %.2e max %.2e; mean |dlogp| %.3e"
           % (r6.mean().item(), r6.flatten().quantile(0.95).item(), r6.max().item(), (lp8 - lpb).abs().mean().item()))
     assert r6.mean().item() < 8e-2 and r6.flatten().quantile(0.95).item() < 0.3
+
+
+def test_7b_unified_scoring_is_bit_identical_to_the_training_forward_at_1024_tokens():
+    """BASELINE's headline shape (7B, 32 frames, G = 8, C = 1024: T = 9280 rows = 36 whole 256-row tiles + a 64-row tail whose
+    o / down projections run as split k-parts): the reference / old-policy scoring pass (Engine.score_unified) and the policy's
+    training forward (Trainer.forward) give IDENTICAL log-probs from identical weights, twice over -- round 3 measured 1.2e-2 mean
+    between the prefix-cache scoring pass and the training forward here (profiles/r03_full_size_entry.md), the size of the KL term
+    itself.  Also at a packed (ragged) row count."""
+    import bench
+    from video_r2_amd import lib, weights as W
+    from video_r2_amd.config import ModelConfig
+    from video_r2_amd.engine import Engine
+    from video_r2_amd.train import Trainer
+    lib.load()
+    dev = "cuda:0"
+    cfg = ModelConfig.qwen25vl_7b()
+    sd = W.random_state_dict(cfg, seed=0, device=dev)
+    vis = W.build_vision(cfg, sd, dev)
+    pol = W.build_text(cfg, sd, dev)
+    del sd
+    torch.cuda.empty_cache()
+    eng = Engine(cfg, vis, pol, device=dev)
+    G, C = 8, 1024
+    px, grid, ids = bench.synth_prompt(cfg, 32, 7, dev)
+    emb, plan = eng.encode_video(px, [grid])
+    emb = emb.clone()
+    g = torch.Generator().manual_seed(3)
+    toks = torch.randint(1000, cfg.image_token_id - 1, (G, C), generator=g, dtype=torch.int32).to(dev)
+    tr = Trainer(eng, pol)
+    for lens in (None, np.asarray([1024, 1000, 17, 640, 1024, 333, 901, 64])):
+        a = eng.score_unified(pol, ids, emb, plan, [1.0], toks, 0.9, tag="ref", lens=lens).clone()
+        b = tr.forward(ids, emb, plan, [1.0], toks, 0.9, lens=lens).clone()
+        a2 = eng.score_unified(pol, ids, emb, plan, [1.0], toks, 0.9, tag="ref", lens=lens).clone()
+        eng.sync()
+        assert torch.isfinite(a).all() and float(a.min()) < -1.0
+        assert torch.equal(a, a2), "the scoring pass is not reproducible from run to run"
+        assert torch.equal(a, b), f"scoring and training forward differ: max {(a - b).abs().max().item():.3e}"

@@ -21,6 +21,22 @@ def test_train_grpo_sh_flags_parse():
         params.parse_args(["--num_generations", "1"])
 
 
+def test_unfreezing_the_vision_side_is_refused_not_downgraded():
+    """reference train_grpo.py:48-57,123-124 trains the vision tower / merger when asked; this engine trains the LM only and must
+    say so with an error instead of silently training another parameter set"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vr2_train_entry", os.path.join(root, "train", "src", "train", "train_grpo.py"))
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    base = "--model_id /m --data_path d.json --freeze_llm False".split()
+    entry.check_trainable_set(params.parse_args(base + "--freeze_vision_tower True --freeze_merger True".split()))
+    for bad in ("--freeze_vision_tower False --freeze_merger True", "--freeze_vision_tower True --freeze_merger False", ""):
+        with pytest.raises(NotImplementedError, match="freeze_"):
+            entry.check_trainable_set(params.parse_args(base + bad.split()))
+
+
 def test_train_grpo_sh_emits_flags_the_parser_accepts(tmp_path):
     """run train/scripts/train_grpo.sh with `python` shimmed by a script that prints its argv: the launcher line must name
     the entry point, and every flag the recipe passes must parse (engine-irrelevant ones land in `ignored`)"""

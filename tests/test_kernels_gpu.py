@@ -122,8 +122,10 @@ def test_gemm_256_tile_swiglu_and_random(dev):
 def test_gemm_main_plus_tail_split(dev, K):
     """M = 9 whole 256-row tiles + 64 tail rows with N = 7168: the full tiling (10 x 28 = 280 tiles, 1.09 rounds) is inefficient,
     the 252 whole tiles fill one round -> 256-row kernel on rows [0, 2304) + 128-row kernel on the tail (gemm.hip launch).
-    K = 2048: the fp32-output tails (56 tiles) are additionally cut into 4 k-parts that add atomically (exact on integers)."""
+    K = 2048: the fp32-output tails (56 tiles) are additionally cut into 4 k-parts, each into a slab of the registered workspace,
+    summed in part order (exact on integers; on random operands identical from run to run -- no atomics)."""
     from video_r2_amd.weights import interleave_gate_up
+    lib.gemm_workspace(dev)
     M, N = 2368, 7168
     g = torch.Generator().manual_seed(4)
     A = torch.randint(-3, 4, (M, K), generator=g).float()
@@ -139,6 +141,24 @@ def test_gemm_main_plus_tail_split(dev, K):
     Cb = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
     lib.call("vr2_gemm_bf16", Ad, K, Wd, None, Cb, N, M, N, K, 0, S())
     assert torch.equal(Cb.float().cpu(), bf(A @ W.t()).float())
+    # random operands: the split tail is deterministic (two launches, identical bits) and right; without a workspace the tail
+    # rows run as full-K tiles (also right)
+    Ar, Wr = bf(torch.randn(M, K, generator=g)), bf(0.05 * torch.randn(N, K, generator=g))
+    refr = Ar.float() @ Wr.float().t() + bias
+    Ard, Wrd = Ar.to(dev), pk(Wr, dev)
+    outs = []
+    for _ in range(3):
+        Cr = torch.empty(M, N, device=dev)
+        lib.call("vr2_gemm_bf16", Ard, K, Wrd, bd, Cr, N, M, N, K, 1, S())
+        outs.append(Cr)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert (outs[0].cpu() - refr).abs().max().item() < 1e-4 * refr.abs().max().item() + 1e-4
+    lib.call("vr2_set_gemm_workspace", None, 0)
+    Cn = torch.empty(M, N, device=dev)
+    lib.call("vr2_gemm_bf16", Ard, K, Wrd, bd, Cn, N, M, N, K, 1, S())
+    lib.gemm_workspace(dev)
+    assert (Cn.cpu() - refr).abs().max().item() < 1e-4 * refr.abs().max().item() + 1e-4
+    assert torch.equal(Cn[:M - 64], outs[0][:M - 64])               # the whole 256-row tiles do not depend on how the tail runs
     # SwiGLU + saved pre-activations: the tail launch must offset the aux buffer too
     I = N // 2
     Wg = bf(0.1 * torch.randn(I, K, generator=g)); Wu = bf(0.1 * torch.randn(I, K, generator=g))

@@ -171,6 +171,39 @@ def test_generate_with_hf_keyword_arguments_as_the_eval_harness_calls_it():
         m.generate(**kw, pixel_values=torch.zeros(4, 1176), max_new_tokens=2)
 
 
+def test_generate_without_a_seed_draws_one_per_call_from_the_global_generator():
+    """HF samples from torch's global RNG: two generate() calls with the same transformers.GenerationConfig (which has no
+    `seed`) give different rollouts, torch.manual_seed() repeats them.  The engine's counter-based stream is keyed per call by a
+    draw from the global CPU generator; an explicit seed pins it."""
+    from types import SimpleNamespace
+    from video_r2_amd.model import GenerationConfig
+    m, w, ocfg = _model(2, 47)
+    cfg = m.cfg
+    g = torch.Generator().manual_seed(6)
+    frames = torch.randint(0, 256, (2, 3, 56, 84), generator=g, dtype=torch.uint8).numpy()
+    px, grid = pixels_from_frames(frames, cfg.vision)
+    tv = grid[0] * grid[1] * grid[2] // 4
+    p = [21, cfg.vision_start_token_id] + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 30, 31, 32]
+    ids = torch.tensor([p, p, p, p])
+    kw = dict(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values_videos=torch.from_numpy(np.concatenate([px] * 4)).cuda(),
+              video_grid_thw=torch.tensor([grid] * 4), second_per_grid_ts=[1.0] * 4)
+    hf_gc = SimpleNamespace(max_new_tokens=12, do_sample=True, temperature=1.0, top_p=1.0, top_k=50, min_p=None, repetition_penalty=1.0,
+                            pad_token_id=cfg.pad_token_id, eos_token_id=[-1], num_beams=1, max_length=None)
+    torch.manual_seed(123)
+    a = m.generate(**kw, generation_config=hf_gc)
+    b = m.generate(**kw, generation_config=hf_gc)
+    assert not torch.equal(a, b)                                   # 4 x 12 draws from 50 candidates each: a collision is impossible
+    torch.manual_seed(123)
+    a2 = m.generate(**kw, generation_config=hf_gc)
+    assert torch.equal(a, a2)                                      # the global seed reproduces the run, as with HF
+    c = m.generate(**kw, do_sample=True, temperature=1.0, top_k=50, max_new_tokens=12, eos_token_id=-1)
+    d = m.generate(**kw, do_sample=True, temperature=1.0, top_k=50, max_new_tokens=12, eos_token_id=-1)
+    assert not torch.equal(c, d)                                   # the keyword-argument form (the eval harness) too
+    e = m.generate(**kw, generation_config=GenerationConfig(max_new_tokens=12, temperature=1.0, eos_token_id=-1, seed=9))
+    f = m.generate(**kw, generation_config=GenerationConfig(max_new_tokens=12, temperature=1.0, eos_token_id=-1, seed=9))
+    assert torch.equal(e, f)                                       # an explicit seed pins the stream
+
+
 def test_save_pretrained_roundtrip(tmp_path):
     from video_r2_amd.model import VideoR2Model
     m, w, ocfg = _model(7, 23)
@@ -213,7 +246,9 @@ def test_trainer_step_metrics_and_loss():
     assert ro["completion_ids"].shape == (4, 12) and ro["logps"].shape == (4, 12) and ro["dlogp"].shape == (4, 12)
     # policy == reference copy at step 0 -> KL exactly 0, ratio exactly 1 -> loss = -mean_g(mean_t(A)) = -mean(A)
     adv = out["advantages"]["advantages"]
-    assert abs(out["metrics"]["kl"]) < 1e-6 and abs(out["loss"] - (-adv.mean().item())) < 1e-5
+    # (EXACTLY: the reference's log-probs come from Engine.score_unified, the row space and launches of the training forward)
+    assert out["metrics"]["kl"] == 0.0 and abs(out["loss"] - (-adv.mean().item())) < 1e-5
+    assert torch.equal(ro["ref_logps"], ro["logps"])
     for k in ("completions/mean_length", "completions/clipped_ratio", "reward", "reward_std", "rewards/format_reward/mean",
               "rewards/accuracy_reward/mean", "clip_ratio/low_mean", "clip_ratio/high_max", "clip_ratio/region_mean", "num_tokens"):
         assert k in out["metrics"], k

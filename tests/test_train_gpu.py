@@ -195,3 +195,31 @@ def test_packed_completions_equal_the_padded_layout(group, lens):
     for k, gd in g_d.items():
         e = (tr.state.grad[k] - gd).norm().item() / max(gd.norm().item(), 1e-20)
         assert e < 2e-3, (k, e)
+
+
+@pytest.mark.parametrize("group,lens", [(2, None), (2, [10, 7, 1]), (7, [3, 0, 10]), (7, None)])
+def test_unified_scoring_is_bit_identical_to_the_training_forward(group, lens):
+    """The two passes whose difference is the loss -- the no-grad scoring of the reference / old policy (Engine.score_unified) and
+    the policy's training forward (Trainer.forward) -- run the same launches over the same row space: with identical weights every
+    log-prob is identical in every bit (kl == 0 and ratio == 1 exactly, as in the reference where both come from one model call,
+    grpo_trainer.py:723-741 at :826 and :1094), for dense and for packed completions, and from run to run."""
+    from video_r2_amd.train import Trainer
+    ocfg, eng, w, cfg, px, grid, prompt, comp = _setup(group, 90 + group)
+    G, C = comp.shape
+    ln = None if lens is None else np.asarray(lens)
+    emb, plan = eng.encode_video(torch.from_numpy(px).to(eng.device), [grid])
+    emb = emb.clone()
+    tr = Trainer(eng, eng.text)
+    a = eng.score_unified(eng.text, prompt, emb, plan, [1.0], comp, 0.9, tag="ref", lens=ln).clone()
+    b = tr.forward(prompt, emb, plan, [1.0], comp, 0.9, lens=ln).clone()
+    a2 = eng.score_unified(eng.text, prompt, emb, plan, [1.0], comp, 0.9, tag="ref", lens=ln).clone()
+    eng.sync()
+    assert torch.equal(a, b) and torch.equal(a, a2)
+    # and it is the same function as the prefix-cache scoring pass, to fp32 summation order
+    st = eng.prefill(eng.text, prompt, emb, plan, [1.0])
+    c = eng.score(eng.text, st, comp, 0.9, lens=ln)
+    eng.sync()
+    assert (a - c).abs().max().item() <= 2e-3 and bool((a != 0).any())
+    if ln is not None:
+        valid = torch.from_numpy(np.arange(C)[None, :] < ln[:, None]).to(a.device)
+        assert not a[~valid].any()

@@ -125,6 +125,20 @@ def prefetched(steps, processing_fn, workers):
             cur, futs = nxt, nfuts
 
 
+def check_trainable_set(args):
+    """The parameter set this engine trains is the LM (decoder layers, embeddings, lm_head); the vision tower and the merger
+    are frozen, as in the shipped recipe (train_grpo.sh: --freeze_vision_tower True --freeze_merger True).  The reference
+    honours --freeze_vision_tower False / --freeze_merger False with their own learning rates (train_grpo.py:48-57,123-124,
+    params.py:55-56); training a different parameter set than the one asked for would be a silent change of the experiment,
+    so those settings are refused."""
+    asked = [f"--{name} False" for name in ("freeze_vision_tower", "freeze_merger") if not getattr(args, name)]
+    if asked:
+        raise NotImplementedError(
+            f"{' and '.join(asked)}: the MI355X engine has no backward pass through the vision tower / merger (head_dim-80 windowed "
+            "attention, GELU merger) -- it trains the LM only.  Pass --freeze_vision_tower True --freeze_merger True (the shipped "
+            "train_grpo.sh recipe), or train the vision side with the reference trainer.")
+
+
 def train(argv=None, processing_fn=None, dataset=None):
     import torch
     from video_r2_amd import dist as vdist
@@ -142,8 +156,7 @@ def train(argv=None, processing_fn=None, dataset=None):
     log = (lambda *a: print("[train_grpo]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
     if args.ignored:
         log(f"flags accepted and ignored by the MI355X engine: {sorted(args.ignored)}")
-    if not args.freeze_vision_tower or not args.freeze_merger:
-        log("note: the vision tower and the merger stay frozen in this engine (the shipped recipe freezes both)")
+    check_trainable_set(args)
     model = VideoR2Model.from_pretrained(args.model_id, device=device)
     if dataset is None:
         if not args.data_path:

@@ -50,7 +50,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {   // 16 B per l
 // wave's first output row / column
 // PRELOADED: the accumulators of an EPI_ADD_F32 launch started from the old output values, nothing is read back here
 // F8: acc holds sums of e4m3 products; value = acc * wscale[n] * xscale[m] (applied here, before bias / activation)
-template <int EPI, int MT, bool ATOMIC = false, bool PRELOADED = false, bool F8 = false>
+template <int EPI, int MT, bool UNUSED = false, bool PRELOADED = false, bool F8 = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, int n0, int wn, int fr, int fq,
                                          const float* __restrict__ bias, void* __restrict__ Cv, long ldc, int M, int N,
                                          bf16* __restrict__ aux, long ldaux, const float* __restrict__ wscale = nullptr,
@@ -141,10 +141,6 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, in
         *reinterpret_cast<bf16x4*>((bf16*)Cv + (long)m * ldc + n) = o;
       } else {
         float* cp = (float*)Cv + (long)m * ldc + n;
-        if (ATOMIC) {   // one k-part of a split-K launch: the parts add into the (zeroed, or residual-holding) fp32 output
-          unsafeAtomicAdd(cp, v0); unsafeAtomicAdd(cp + 1, v1); unsafeAtomicAdd(cp + 2, v2); unsafeAtomicAdd(cp + 3, v3);
-          continue;
-        }
         if (EPI == EPI_ADD_F32 && !PRELOADED) {
           const float4 old = *reinterpret_cast<const float4*>(cp);
           v0 += old.x; v1 += old.y; v2 += old.z; v3 += old.w;
@@ -158,7 +154,11 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[4][MT], int mw, int nw, in
 // MT = 16-row activation fragments per wave: workgroup tile BM x 128 with BM = 32*MT (128 for big grids; 64 when the 128-row
 // grid would leave CUs with fewer than ~2 workgroups -- prefill at M = S ~ 1k rows, ViT projections with N = 1280)
 // SPLIT: gridDim.z k-parts of a launch with too few output tiles to fill the chip (the < 256 tail rows of a 256-row tiling at
-// N = 3584 are 28 tiles, each walking the whole K: 0.47 ms at K = 37888 on 28 CUs); fp32 outputs only, the parts add atomically
+// N = 3584 are 28 tiles, each walking the whole K: 0.47 ms at K = 37888 on 28 CUs); fp32 outputs only.  Every part stores its
+// partial tile into a slab of its own (Cv = the slab workspace: [part][tile][64][128] fp32) and splitk_reduce_kernel adds the
+// parts in part order: the result does not depend on which part finishes first (rounds 1-3 added the parts with fp32 atomics:
+// the tail rows of a forward pass then differed in their last bits from run to run, and with them the log-probs of two passes
+// over the same weights)
 // F8: A / Wp are e4m3 bytes addressed as pairs (lda, K in 2-byte units = half the fp8 counts), see the file header
 template <int EPI, int MT, bool SPLIT = false, bool F8 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, long lda, const bf16* __restrict__ Wp,
@@ -270,13 +270,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
     __syncthreads();                                   // ... for every wave, and tile t is fully consumed
   }
 
-  epilogue<EPI, MT, SPLIT, false, F8>(acc, m0 + wm * (16 * MT), n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux, wscale, xscale);
+  if constexpr (SPLIT) {
+    // slab tile of this (part, tile): rows m0.., columns n0.. of a [BM_][128] fp32 block; the plain-store epilogue addresses it
+    // through a base shifted by the tile's origin
+    const long tile = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* slab = (float*)Cv + tile * (BM_ * BN) - ((long)m0 * BN + n0);
+    epilogue<EPI_F32, MT, false, false, F8>(acc, m0 + wm * (16 * MT), n0 + wn * 64, n0, wn, fr, fq, bias, slab, BN, M, N, nullptr, 0, wscale, xscale);
+  } else {
+    epilogue<EPI, MT, false, false, F8>(acc, m0 + wm * (16 * MT), n0 + wn * 64, n0, wn, fr, fq, bias, Cv, ldc, M, N, aux, ldaux, wscale, xscale);
+  }
 }
 
-__global__ __launch_bounds__(256) void zero_rows_f32_kernel(float* __restrict__ C, long ldc, int N) {
-  float* row = C + (long)blockIdx.x * ldc;
-  for (int n = threadIdx.x * 4; n < N; n += 1024) *reinterpret_cast<float4*>(row + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+// C (+)= sum over the k-parts of a SPLIT launch, in part order; one workgroup per 64 x 128 output tile
+template <bool ADD>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int parts, float* __restrict__ C, long ldc, int M, int N) {
+  const long tiles = (long)gridDim.x * gridDim.y, tile = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int e = (i * 256 + threadIdx.x) * 4, r = e >> 7, c = e & 127;
+    const int m = m0 + r, n = n0 + c;
+    if (m >= M || n >= N) continue;
+    float* cp = C + (long)m * ldc + n;
+    float4 v = ADD ? *reinterpret_cast<const float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < parts; ++p) {
+      const float4 s = *reinterpret_cast<const float4*>(slabs + (p * tiles + tile) * (64 * BN) + e);
+      v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+    }
+    *reinterpret_cast<float4*>(cp) = v;
+  }
 }
+
+// slab workspace of the SPLIT launches, owned by the caller (vr2_set_gemm_workspace): a launch needs parts x tiles x 32 KiB
+// <= 256 x 32 KiB = 8 MiB; without one the tail rows run as full-K tiles (slower, still deterministic)
+float* g_split_ws = nullptr;
+int64_t g_split_ws_bytes = 0;
 
 // ---- 256 x 256 x 64 tile, 8 waves (2 M x 4 N, 128 x 64 outputs each), for grids of >= 2 such tiles per CU ----------------
 // LDS (128 KiB): 2 buffers (k-tile parity) x [X-lo 16K | X-hi 16K | W-lo 16K | W-hi 16K]; X halves are 128 activation rows x 64 k
@@ -438,7 +466,8 @@ void launch128(const void* A, int64_t lda, const void* W, const void* bias, void
   }
 }
 
-// few rows (a tail of <= 128), fp32 output, long K: 64-row tiles with the k-tiles dealt to enough parts to fill the CUs
+// few rows (a tail of <= 128), fp32 output, long K: 64-row tiles with the k-tiles dealt to enough parts to fill the CUs, each
+// part into its own slab, summed in part order by splitk_reduce_kernel
 template <int EPI, bool F8 = false>
 bool launch_tail_splitk(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc, int64_t M, int64_t N,
                         int64_t K, void* stream, const float* ws = nullptr, const float* xs = nullptr) {
@@ -448,11 +477,13 @@ bool launch_tail_splitk(const void* A, int64_t lda, const void* W, const void* b
     if (parts > kt / 4) parts = kt / 4;
     if (parts > 32) parts = 32;
     if (parts < 2) return false;
-    if (EPI == EPI_F32) hipLaunchKernelGGL(zero_rows_f32_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, (float*)C, (long)ldc, (int)N);
+    if (g_split_ws == nullptr || g_split_ws_bytes < (int64_t)parts * nb * mb * 64 * BN * 4) return false;
     dim3 grid((unsigned)nb, (unsigned)mb, (unsigned)parts);
     hipLaunchKernelGGL((gemm_kernel<EPI, 2, true, F8>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16*)A, (long)lda,
-                       (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, C, (long)ldc, (int)M, (int)N, (int)K,
+                       (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, (void*)g_split_ws, (long)ldc, (int)M, (int)N, (int)K,
                        (bf16*)nullptr, 0L, ws, xs);
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI == EPI_ADD_F32>), dim3((unsigned)nb, (unsigned)mb), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)g_split_ws, (int)parts, (float*)C, (long)ldc, (int)M, (int)N);
     return true;
   } else {
     return false;
@@ -505,6 +536,15 @@ int launch(const void* A, int64_t lda, const void* W, const void* bias, void* C,
 }
 
 }  // namespace
+
+// fp32 scratch for the k-parts of split launches (8 MiB covers every shape; see g_split_ws).  The caller owns the memory, keeps it
+// alive while GEMMs run and uses ONE stream per workspace.  ptr = NULL unregisters it.
+extern "C" int vr2_set_gemm_workspace(void* ptr, int64_t bytes) {
+  VR2_REQUIRE((ptr == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)ptr & 15) == 0, "vr2_set_gemm_workspace: bad workspace (%p, %ld bytes)", ptr, (long)bytes);
+  g_split_ws = (float*)ptr;
+  g_split_ws_bytes = bytes;
+  return 0;
+}
 
 extern "C" int vr2_gemm_bf16(const void* A, int64_t lda, const void* Wpacked, const void* bias_f32, void* C, int64_t ldc,
                              int64_t M, int64_t N, int64_t K, int epilogue, void* stream) {

@@ -69,6 +69,7 @@ class Engine:
         if not torch.cuda.is_available():
             raise lib.Vr2Error("video_r2_amd.Engine needs an MI355X (no CPU fallback)")
         lib.load()
+        lib.gemm_workspace(device)      # slabs of the GEMMs' deterministic split-K tails (vr2_set_gemm_workspace)
         self.cfg = cfg
         self.vision = vision
         self.text = text
@@ -465,10 +466,17 @@ class Engine:
             self._gemm(act, W, f"l{l}.down_w", None, x, T, EPI_ADD_F32)
         return x
 
-    def _logits_rows(self, W: Params, x, T, out):
+    def _logits_rows(self, W: Params, x, T, out, xn=None, allow_f8=True):
+        """final norm + lm_head over T rows -> fp32 logits in ``out``.  xn: bf16 [T][H] of the caller to receive the normed rows
+        (the training forward keeps them for the lm_head weight gradient; it also passes allow_f8=False: config 5's fp8 GEMMs
+        are for the no-grad passes only)."""
         t = self.cfg.text
-        xn = self.buf("lm.hn%d" % T, (T, t.hidden_size), torch.bfloat16)
-        if T > 16 and self._lm_f8(W) and "lm_head" in W.f8:
+        # capacity semantics like every workspace: ONE buffer for the chunked callers (scoring: sum(lens) % 1024 differs for almost
+        # every group) and one for the few-row callers (prompt-last rows); a name per row count leaked a buffer per distinct T
+        # and bumped _ws_epoch each time, which drops the captured decode graphs
+        if xn is None:
+            xn = self.buf("lm.hn" if T > 128 else "lm.hn.s", (T, t.hidden_size), torch.bfloat16)
+        if allow_f8 and T > 16 and self._lm_f8(W) and "lm_head" in W.f8:
             qx = self._quant_rows(None, T, 0, "lm")
             self._norm(x, W["norm"], xn, T, t.hidden_size, t.rms_norm_eps, q8=qx)
             self._gemm8(*qx, W, "lm_head", None, out, T, EPI_F32)
@@ -764,7 +772,7 @@ class Engine:
         # a teacher-forced row goes on whatever the sampler drew -- and not with EOS off
         b["skip_finished"] = b["finished"] if (forced_tokens is None and (eos >= 0 or finish_at is not None)) else None
         d_finish = None if finish_at is None else torch.as_tensor(np.asarray(finish_at), dtype=torch.int32).to(self.device)
-        b["plen"] = self.buf("d.plen%d" % P, (P,), torch.int32)
+        b["plen"] = self.buf("d.plen", (P,), torch.int32)
         pos0 = torch.tensor([s_.n_prompt + s_.rope_delta for s_ in states for _ in range(G)], dtype=torch.int32)
         plen = torch.tensor([s_.n_prompt for s_ in states], dtype=torch.int32)
         logits0 = self.buf("d.logits0", (NG, V), torch.float32)
@@ -862,6 +870,116 @@ class Engine:
         first = offs[lens > 0]
         src[first] = -1
         return dict(lens=lens, offs=offs, R=R, sel=sel.astype(np.int64), first=first.astype(np.int64), src=src)
+
+    HEAD_CHUNK = 4096     # rows per lm_head launch of the unified passes: 4096 x 152064 fp32 = 2.5 GB, full 256-row tiles
+
+    def unified_layout(self, prompt_ids, plan, second_per_grid_ts, video_embeds, completion_ids, lens=None):
+        """The ONE row space of a prompt group's teacher-forced pass: T = S + R rows = the S prompt rows (causal among themselves)
+        followed by the completion rows of each of the G sequences (each sees the whole prompt + its own causal prefix), the
+        sequences cut at lens[g] and packed back to back when lens is given.  Both passes whose difference is the loss -- the
+        no-grad scoring (score_unified: reference model, old policy) and the training forward (train.Trainer.forward) -- are laid
+        out by THIS function and run the same launches over it, so that identical weights give identical bits at every shape."""
+        ids = np.asarray(prompt_ids, dtype=np.int64).reshape(-1)
+        S = int(ids.shape[0])
+        comp = torch.as_tensor(np.asarray(completion_ids) if not torch.is_tensor(completion_ids) else completion_ids)
+        comp = comp.to(device=self.device, dtype=torch.int32).contiguous()
+        G, C = comp.shape
+        if lens is not None and int(np.asarray(lens).sum()) == G * C:
+            lens = None                                           # nothing to cut: the dense layout
+        lay = None if lens is None else self.ragged_layout(G, C, lens)
+        R = G * C if lay is None else lay["R"]
+        seq_len = [C] * G if lay is None else [int(n) for n in lay["lens"]]
+        seq_off = [g * C for g in range(G)] if lay is None else [int(o) for o in lay["offs"]]    # first row of a sequence, from S
+        pos, delta, vid_pos = self.vision_layout(ids, plan, second_per_grid_ts, video_embeds)
+        pc = np.concatenate([np.arange(n, dtype=np.int64) + S + delta for n in seq_len]) if R else np.zeros(0, dtype=np.int64)
+        pos_all = np.concatenate([pos, np.broadcast_to(pc[None, :], (3, R))], 1)
+        d_sel = None if lay is None else torch.from_numpy(lay["sel"]).to(self.device)
+        tok = comp.view(-1) if lay is None else comp.view(-1).index_select(0, d_sel).contiguous()
+        work = vp.heaviest_first(np.concatenate([vp.causal_work(S, 0, 0, 0, 0, q_tile=vp.LM_Q_TILE)] +
+                                                [vp.causal_work(n, S + o, 0, S, S + o, q_tile=vp.LM_Q_TILE) for n, o in zip(seq_len, seq_off) if n > 0], 0))
+        # head row r is predicted by x row S + r - 1, a sequence's first row by the prompt's last row
+        if lay is None:
+            src = np.arange(R, dtype=np.int64) - 1
+            src[np.arange(G) * C] = -1
+            first = np.arange(G, dtype=np.int64) * C
+        else:
+            src, first = lay["src"], lay["first"]
+        pred = torch.from_numpy(np.where(src < 0, S - 1, S + src)).to(self.device)
+        return dict(ids=ids, S=S, G=G, C=C, R=R, T=S + R, lay=lay, seq_len=seq_len, seq_off=seq_off, pos_all=pos_all, vid_pos=vid_pos,
+                    sel=d_sel, tok=tok, all_ids=torch.cat([_i32(ids, self.device), tok]), work=_i32(work, self.device), pred=pred,
+                    first=torch.from_numpy(np.asarray(first, dtype=np.int64)).to(self.device))
+
+    def unified_inputs(self, W: Params, u, video_embeds, plan, tag):
+        """embedding rows (+ the scattered vision features) and the rotary tables of a unified row space -> (x f32 [T][H], cos, sin)"""
+        t = self.cfg.text
+        T, H, hd = u["T"], t.hidden_size, t.head_dim
+        x = self.buf(tag + ".x", (T, H), torch.float32)
+        lib.call("vr2_embed_rows", u["all_ids"], W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, self.s)
+        if video_embeds is not None:
+            dst = _i32(u["vid_pos"][plan.window_index], self.device)
+            lib.call("vr2_scatter_rows_f32", video_embeds, video_embeds.stride(0), dst, x, x.stride(0), u["vid_pos"].shape[0], H, self.s)
+        cos = self.buf(tag + ".cos", (T, hd // 2), torch.float32)
+        sin = self.buf(tag + ".sin", (T, hd // 2), torch.float32)
+        lib.call("vr2_mrope_table", _i32(u["pos_all"], self.device), T, self.inv_freq, self.section, cos, sin, hd, self.s)
+        return x, cos, sin
+
+    def head_logps(self, W: Params, hs, u, temperature, logp, hn=None, logits_all=None, lse_out=None, allow_f8=True):
+        """log-prob head over the R gathered rows hs (fp32): final norm, lm_head in HEAD_CHUNK-row launches, log-softmax at the
+        given token -> logp[R].  hn / logits_all / lse_out: buffers of the training forward that keep the normed rows, the logits
+        and the log-sum-exps for its backward."""
+        V = self.cfg.text.vocab_size
+        R = u["R"]
+        rc = min(self.HEAD_CHUNK, R)
+        lg = None if logits_all is not None else self.buf("lm.chunk_logits", (rc, V), torch.float32)
+        for r0 in range(0, R, rc):
+            n = min(rc, R - r0)
+            if logits_all is not None:
+                lg = logits_all[r0:r0 + n]
+            self._logits_rows(W, hs[r0:r0 + n], n, lg, xn=None if hn is None else hn[r0:r0 + n], allow_f8=allow_f8)
+            lib.call("vr2_lse_gather", lg, lg.stride(0), n, V, u["tok"][r0:r0 + n], temperature, logp[r0:r0 + n],
+                     None if lse_out is None else lse_out[r0:r0 + n], self.s)
+
+    def unified_logps_out(self, u, logp):
+        """packed log-probs [R] -> f32 [G, C] (0 at the positions behind a sequence's length)"""
+        if u["lay"] is None:
+            return logp.view(u["G"], u["C"])
+        out = torch.zeros(u["G"] * u["C"], dtype=torch.float32, device=self.device)
+        out.index_copy_(0, u["sel"], logp)
+        return out.view(u["G"], u["C"])
+
+    @_on_stream
+    def score_unified(self, W: Params, prompt_ids, video_embeds, plan, second_per_grid_ts, completion_ids, temperature, tag="ref", lens=None,
+                      allow_fp8=True):
+        """Per-token log-probs f32 [G, C] of ``_get_per_token_logps`` (grpo_trainer.py:723-741) for one prompt group, computed over
+        the unified [prompt | completions] row space -- the SAME row space, work list and launches as the policy's training forward
+        (train.Trainer.forward), without saved activations.  This is the pass for the log-probs that enter the loss beside the
+        policy's: the frozen reference model (:826) and the old policy (:814-821).  With identical weights the two passes give
+        identical bits at every shape (so kl == 0 and ratio == 1 exactly where the reference has them exactly), which the
+        prefix-cache pass (``score``: fewer rows, other tilings, other k orders in the tile tails) does not.
+        Cost: the S prompt rows are recomputed here instead of read from a prefix cache -- the row count a prompt prefill plus a
+        cached scoring pass have together.
+        allow_fp8=False keeps this call on the bf16 GEMMs although the engine's gemm_fp8 mode (config 5) is on: the old-policy
+        log-probs must come from the arithmetic of the training forward (bf16), or the first-iteration ratio is not 1."""
+        t = self.cfg.text
+        H, hd, nkv = t.hidden_size, t.head_dim, t.num_key_value_heads
+        u = self.unified_layout(prompt_ids, plan, second_per_grid_ts, video_embeds, completion_ids, lens)
+        if u["R"] == 0:
+            return torch.zeros((u["G"], u["C"]), dtype=torch.float32, device=self.device)
+        T, R = u["T"], u["R"]
+        mode = self.gemm_fp8
+        self.gemm_fp8 = mode and allow_fp8
+        try:
+            x, cos, sin = self.unified_inputs(W, u, video_embeds, plan, tag + ".u")
+            ks = self.buf(tag + ".uk", (T, nkv * hd), torch.bfloat16)
+            vs = self.buf(tag + ".uv", (T, nkv * hd), torch.bfloat16)
+            self._lm_rows(W, x, T, cos, sin, u["work"], None, None, ks, vs, 0, tag + ".u")
+            hs = self.buf(tag + ".uhs", (R, H), torch.float32)
+            torch.index_select(x, 0, u["pred"], out=hs)
+            logp = self.buf(tag + ".ulogp", (R,), torch.float32)
+            self.head_logps(W, hs, u, temperature, logp)
+        finally:
+            self.gemm_fp8 = mode
+        return self.unified_logps_out(u, logp)
 
     @_on_stream
     def score(self, W: Params, st: PromptState, completion_ids, temperature, tag="pol", row_chunk=1024, return_logits=False, lens=None):

@@ -29,7 +29,6 @@ under the overlays; the integer helpers -- time formatting, SRT parsing, cue loo
 """
 from __future__ import annotations
 
-import bisect
 import json
 import math
 import os
@@ -202,63 +201,84 @@ def draw_timestamp(frame, text):
     return np.asarray(img)
 
 
-def _srt_seconds(ts):
-    hh, mm, rest = ts.split(":")
-    ss, ms = rest.split(",")
-    return int(hh) * 3600 + int(mm) * 60 + int(ss) + int(ms) / 1000.0
+_SRT_CLOCK = re.compile(r"^\s*([+-]?\d+)\s*:\s*([+-]?\d+)\s*:\s*([+-]?\d+)\s*,\s*([+-]?\d+)\s*$")
+_SRT_TAG = re.compile(r"</?[biu]>", re.IGNORECASE)
+
+
+def _srt_clock(field):
+    """'HH:MM:SS,mmm' -> seconds (the milliseconds field is an integer count of ms whatever its width); None if malformed."""
+    m = _SRT_CLOCK.match(field)
+    if m is None:
+        return None
+    hh, mm, ss, ms = (int(g) for g in m.groups())
+    return hh * 3600 + mm * 60 + ss + ms / 1000.0
 
 
 def parse_srt(path):
-    """-> [(start s, end s, [lines])] sorted by start; blocks without a '-->' line in their first three lines, unparsable
-    times and empty texts are skipped; <i>/<b>/<u> tags are stripped (vision_process.py:146-190)."""
-    try:
-        raw = open(path, "r", encoding="utf-8").read()
-    except UnicodeDecodeError:
-        raw = open(path, "r", encoding="utf-8-sig").read()
-    raw = raw.replace("\r\n", "\n").replace("\r", "\n")
-    cues = []
-    for block in (b.strip() for b in raw.split("\n\n")):
-        if not block:
-            continue
-        lines = block.split("\n")
-        at = next((i for i, ln in enumerate(lines[:3]) if "-->" in ln), -1)
-        if at < 0:
-            continue
+    """SubRip file -> [(start s, end s, [text lines])] ordered by start time.
+
+    Behaviour of the reference's parser (vision_process.py:145-186): blocks are separated by blank lines; the timing line is the
+    first of a block's first three lines that holds '-->' (an index line may or may not precede it); a block with no such line,
+    with a timing line that is not exactly two 'HH:MM:SS,mmm' clocks, or with no text is dropped; <i> <b> <u> tags are removed;
+    a UTF-8 byte-order mark and CR / CRLF line ends are accepted."""
+    with open(path, "rb") as f:
+        data = f.read()
+    raw = None
+    for codec in ("utf-8", "utf-8-sig"):                                # the reference's order: plain first, BOM-aware second
         try:
-            a, b = (x.strip() for x in lines[at].strip().split("-->"))
-            start, end = _srt_seconds(a), _srt_seconds(b)
-        except Exception:
+            raw = data.decode(codec)
+            break
+        except UnicodeDecodeError as err:
+            last = err
+    if raw is None:
+        raise last
+    cues = []
+    for block in re.split(r"\n{2,}", re.sub(r"\r\n?", "\n", raw)):
+        rows = block.strip().split("\n")
+        timing = [k for k, row in enumerate(rows[:3]) if "-->" in row]
+        if not timing:
             continue
-        text = [re.sub(r"</?[biu]>", "", ln.strip(), flags=re.IGNORECASE) for ln in lines[at + 1:] if ln.strip()]
+        clocks = [_srt_clock(f) for f in rows[timing[0]].split("-->")]
+        if len(clocks) != 2 or None in clocks:
+            continue
+        text = [_SRT_TAG.sub("", row.strip()) for row in rows[timing[0] + 1:] if row.strip()]
         if text:
-            cues.append((start, end, text))
-    cues.sort(key=lambda c: c[0])
-    return cues
+            cues.append((clocks[0], clocks[1], text))
+    return sorted(cues, key=lambda c: c[0])                             # stable: equal starts keep file order
 
 
-class SubtitleIndex:
-    """Cue active at time t (50 ms tolerance), queried with non-decreasing t (vision_process.py:193-219)."""
+class SubtitleTrack:
+    """Which cue is on screen at a frame time.  Stateless: cue start / end times live in two arrays and a query is a
+    ``numpy.searchsorted`` over the starts, so a whole clip's frame times are resolved in one call (``texts``).
 
-    def __init__(self, cues):
-        self.cues = cues
-        self.starts = [c[0] for c in cues]
+    Rule (what vision_process.py:189-212 computes for the non-decreasing frame times the reader feeds it, tol = 50 ms): the
+    candidate is the LAST cue whose start is <= t + tol; it is shown while t < its end + tol.  Overlapping cues: the later
+    start wins and an earlier cue that is still running behind an ended later one is not shown.  A candidate whose start lies
+    ahead of t although it has already "ended" (end < start - tol: a malformed cue) hands over to the cue before it."""
 
-    def get(self, t, last=0, tol=0.05):
-        if not self.cues:
-            return None, last
-        i = bisect.bisect_right(self.starts, t + tol, lo=last) - 1
-        if 0 <= i < len(self.cues):
-            s, e, lines = self.cues[i]
-            if s - tol <= t < e + tol:
-                return "\n".join(lines), i
-            if t < s:
-                j = max(0, i - 1)
-                s2, e2, l2 = self.cues[j]
-                if s2 - tol <= t < e2 + tol:
-                    return "\n".join(l2), j
-        if i < 0 and self.cues[0][0] - t <= tol:
-            return "\n".join(self.cues[0][2]), 0
-        return None, max(0, i)
+    def __init__(self, cues, tol=0.05):
+        self.text = ["\n".join(c[2]) for c in cues]
+        self.start = np.asarray([c[0] for c in cues], dtype=np.float64)
+        self.end = np.asarray([c[1] for c in cues], dtype=np.float64)
+        self.tol = float(tol)
+
+    def lookup(self, times):
+        """times [n] (seconds) -> int64 [n]: index of the cue shown at each time, -1 for none."""
+        t = np.atleast_1d(np.asarray(times, dtype=np.float64))
+        if not self.text:
+            return np.full(t.shape, -1, dtype=np.int64)
+        cand = np.searchsorted(self.start, t + self.tol, side="right") - 1
+        c = np.maximum(cand, 0)
+        on = (cand >= 0) & (self.start[c] - self.tol <= t) & (t < self.end[c] + self.tol)
+        prev = np.maximum(c - 1, 0)
+        handed = (cand >= 0) & ~on & (t < self.start[c]) & (self.start[prev] - self.tol <= t) & (t < self.end[prev] + self.tol)
+        return np.where(on, c, np.where(handed, prev, -1)).astype(np.int64)
+
+    def texts(self, times):
+        return [self.text[i] if i >= 0 else None for i in self.lookup(times)]
+
+    def at(self, t):
+        return self.texts([t])[0]
 
 
 def _text_size(draw, font, text):
@@ -267,22 +287,19 @@ def _text_size(draw, font, text):
 
 
 def wrap_words(draw, font, text, max_width):
-    """Greedy word wrap that keeps explicit line breaks (vision_process.py:228-248)."""
-    out = []
-    for para in text.split("\n"):
-        words = para.split()
-        if not words:
-            out.append("")
-            continue
-        cur = words[0]
-        for w in words[1:]:
-            if _text_size(draw, font, cur + " " + w)[0] <= max_width:
-                cur = cur + " " + w
-            else:
-                out.append(cur)
-                cur = w
-        out.append(cur)
-    return out
+    """Lay text out in lines no wider than max_width pixels: explicit line breaks are kept (an empty paragraph is an empty
+    line), words are never split, a line takes words while it still fits (the greedy rule of vision_process.py:221-240)."""
+    fits = lambda words: _text_size(draw, font, " ".join(words))[0] <= max_width
+    lines = []
+    for paragraph in text.split("\n"):
+        row = []
+        for word in paragraph.split():
+            if row and not fits(row + [word]):
+                lines.append(" ".join(row))
+                row = []
+            row.append(word)
+        lines.append(" ".join(row))
+    return lines
 
 
 def draw_subtitle(frame, text):
@@ -333,9 +350,8 @@ def read_video(ele, clip=None):
         srt = ele["subtitles"] if "subtitles" in ele else (os.path.splitext(path)[0] + ".srt")
         if srt is not None and os.path.exists(srt):
             try:
-                index, at = SubtitleIndex(parse_srt(str(srt))), 0
-                for k, i in enumerate(idx):
-                    text, at = index.get(i / fps, at)
+                shown = SubtitleTrack(parse_srt(str(srt))).texts(np.asarray(idx, dtype=np.float64) / fps)
+                for k, text in enumerate(shown):
                     if text:
                         fr[k] = draw_subtitle(fr[k], text)
             except Exception as e:                                      # a bad subtitle file must not stop training

@@ -88,5 +88,23 @@ def call(name, *args):
     return rc
 
 
+_gemm_ws = {}
+
+
+def gemm_workspace(device):
+    """Register (once per process and device) the fp32 scratch of the GEMMs' split launches (vr2_set_gemm_workspace).  The
+    buffer is process-global like the library's pointer to it and is never freed: an Engine that went away must not leave the
+    library with a pointer into memory the allocator has handed to someone else."""
+    import torch
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = torch.empty(16 << 20, dtype=torch.uint8, device=dev)
+        _gemm_ws[key] = ws
+    call("vr2_set_gemm_workspace", ws, ws.numel())
+    return ws
+
+
 def version():
     return load().vr2_version()

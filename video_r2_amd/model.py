@@ -35,7 +35,9 @@ class GenerationConfig:
     repetition_penalty: float = 1.0
     pad_token_id: int | None = None
     eos_token_id: int | None = None
-    seed: int = 0
+    seed: int | None = None      # None: every generate() call draws its own seed from torch's global CPU generator (HF draws its
+                                 # samples from the global RNG: torch.manual_seed makes a run repeatable, two calls differ); an int
+                                 # pins the call's Philox stream exactly
 
 
 def _groups(ids, mask, same_video=None):
@@ -218,6 +220,13 @@ class VideoR2Model:
             raise ValueError(f"num_beams={hf_kwargs['num_beams']}: the engine samples or decodes greedily, it has no beam search")
         if isinstance(gc.eos_token_id, (list, tuple)):
             gc.eos_token_id = gc.eos_token_id[0]                 # one stop id (the tokenizer's, as the trainer and the harness pass it)
+        if hf_kwargs.get("seed") is not None:
+            gc.seed = int(hf_kwargs["seed"])
+        if gc.seed is None:
+            # HF's transformers.GenerationConfig carries no seed and neither do the harness's keyword arguments: one draw from the
+            # global CPU generator per call keys the device's counter-based stream, so a prompt revisited in a later epoch gets new
+            # rollouts and torch.manual_seed() still reproduces the run (the trainer passes its own per-step seeds to the engine)
+            gc.seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         cfg = self.cfg
         ids = input_ids.cpu().numpy()
         mask = np.ones_like(ids) if attention_mask is None else attention_mask.cpu().numpy()

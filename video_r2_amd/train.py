@@ -147,37 +147,16 @@ class Trainer:
         H, hd, nq, nkv, I, V, L = t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size, t.vocab_size, t.num_hidden_layers
         I16 = (I + 15) // 16 * 16
         nqkv = (nq + 2 * nkv) * hd
-        ids = np.asarray(prompt_ids, dtype=np.int64).reshape(-1)
-        S = int(ids.shape[0])
-        comp = torch.as_tensor(completion_ids).to(device=eng.device, dtype=torch.int32).contiguous()
-        G, C = comp.shape
-        if lens is not None and int(np.asarray(lens).sum()) == G * C:
-            lens = None                                           # nothing to cut: the dense layout
-        lay = None if lens is None else Engine.ragged_layout(G, C, lens)
-        if lay is not None and lay["R"] == 0:
+        # row space, positions, attention work list and head gather: Engine.unified_layout, shared with Engine.score_unified (the
+        # no-grad pass of the reference / old-policy log-probs) so that the two passes run the same launches on the same rows
+        u = eng.unified_layout(prompt_ids, plan, second_per_grid_ts, video_embeds, completion_ids, lens)
+        if u["R"] == 0:
             raise ValueError("forward(): every completion has length 0 -- nothing to train on")
-        R = G * C if lay is None else lay["R"]
-        seq_len = [C] * G if lay is None else [int(n) for n in lay["lens"]]
-        seq_off = [g * C for g in range(G)] if lay is None else [int(o) for o in lay["offs"]]    # first row of a sequence, from S
-        T = S + R
-        pos, delta, vid_pos = eng.vision_layout(ids, plan, second_per_grid_ts, video_embeds)
-        pc = np.concatenate([np.arange(n, dtype=np.int64) + S + delta for n in seq_len])
-        pos_all = np.concatenate([pos, np.broadcast_to(pc[None, :], (3, R))], 1)
-        d_sel = None if lay is None else torch.from_numpy(lay["sel"]).to(eng.device)
-        tok = comp.view(-1) if lay is None else comp.view(-1).index_select(0, d_sel).contiguous()
-        all_ids = torch.cat([_i32(ids, eng.device), tok])
+        S, G, C, R, T, lay = u["S"], u["G"], u["C"], u["R"], u["T"], u["lay"]
+        tok, all_ids, d_work, d_sel = u["tok"], u["all_ids"], u["work"], u["sel"]
         b = eng.buf
-        x = b("t.x", (T, H), torch.float32)
-        lib.call("vr2_embed_rows", all_ids, W["embed"], W["embed"].stride(0), x, x.stride(0), T, H, eng.s)
-        if video_embeds is not None:
-            dst = _i32(vid_pos[plan.window_index], eng.device)
-            lib.call("vr2_scatter_rows_f32", video_embeds, video_embeds.stride(0), dst, x, x.stride(0), vid_pos.shape[0], H, eng.s)
-        cos = b("t.cos", (T, hd // 2), torch.float32); sin = b("t.sin", (T, hd // 2), torch.float32)
-        lib.call("vr2_mrope_table", _i32(pos_all, eng.device), T, eng.inv_freq, eng.section, cos, sin, hd, eng.s)
-        work = vp.heaviest_first(np.concatenate([vp.causal_work(S, 0, 0, 0, 0, q_tile=vp.LM_Q_TILE)] +
-                                                [vp.causal_work(n, S + o, 0, S, S + o, q_tile=vp.LM_Q_TILE) for n, o in zip(seq_len, seq_off) if n > 0], 0))
-        d_work = _i32(work, eng.device)
-        kwork = _i32(vp.key_work(S, G, C, group=t.group, lens=None if lay is None else seq_len), eng.device)
+        x, cos, sin = eng.unified_inputs(W, u, video_embeds, plan, "t")
+        kwork = _i32(vp.key_work(S, G, C, group=t.group, lens=None if lay is None else u["seq_len"]), eng.device)
         sv = dict(x_in=b("t.x_in", (L, T, H), torch.float32), xn1=b("t.xn1", (L, T, H), torch.bfloat16),
                   q=b("t.q", (L, T, nq * hd), torch.bfloat16), k=b("t.k", (L, T, nkv * hd), torch.bfloat16),
                   v=b("t.v", (L, T, nkv * hd), torch.bfloat16), att=b("t.att", (L, T, nq * hd), torch.bfloat16),
@@ -208,38 +187,19 @@ class Trainer:
             self._gemm(act, f"l{l}.down_w", None, x, T, EPI_ADD_F32)
         # log-prob head: row (g, j) is predicted by the prompt's last row (j == 0) or completion row (g, j-1)
         hs = b("t.hs", (R, H), torch.float32)
-        pred = None
-        if lay is None:
-            hv, xc = hs.view(G, C, H), x[S:].view(G, C, H)
-            hv[:, 1:].copy_(xc[:, :-1])
-            hv[:, 0].copy_(x[S - 1:S].expand(G, H))
-        else:   # packed rows: row r of the head reads row S + r - 1 of x; a sequence's first row reads the prompt's last row
-            pred = torch.from_numpy(np.where(lay["src"] < 0, S - 1, S + lay["src"])).to(eng.device)
-            torch.index_select(x, 0, pred, out=hs)
+        torch.index_select(x, 0, u["pred"], out=hs)
         hn = b("t.hn", (R, H), torch.bfloat16)
-        eng._norm(hs, W["norm"], hn, R, H, t.rms_norm_eps)
         logp = b("t.logp", (R,), torch.float32)
         lse_out = b("t.lse_out", (R,), torch.float32)
-        rc = min(4096, R)        # rows per logits chunk: 4096 x 152064 fp32 = 2.5 GB; keeps the head GEMMs on 256-row tiles
         # the group's logits stay in memory for the backward when they fit KEEP_LOGITS_BYTES (7B, G x C = 8192 rows: 5 GB): the
         # head backward then reads them instead of multiplying hn by the lm_head a second time
         keep = R * V * 4 <= self.KEEP_LOGITS_BYTES
         lg_all = b("t.logits", (R, V), torch.float32) if keep else None
-        lg = None if keep else b("lm.chunk_logits", (rc, V), torch.float32)
-        for r0 in range(0, R, rc):
-            n = min(rc, R - r0)
-            if keep:
-                lg = lg_all[r0:r0 + n]
-            self._gemm(hn[r0:r0 + n], "lm_head", None, lg, n, EPI_F32)
-            lib.call("vr2_lse_gather", lg, lg.stride(0), n, V, tok[r0:r0 + n], temperature, logp[r0:r0 + n], lse_out[r0:r0 + n], eng.s)
+        eng.head_logps(W, hs, u, temperature, logp, hn=hn, logits_all=lg_all, lse_out=lse_out, allow_f8=False)
         self._saved = dict(logits=lg_all, sv=sv, S=S, G=G, C=C, T=T, R=R, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
-                           lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None, sel=d_sel, pred=pred,
-                           first=None if lay is None else torch.from_numpy(lay["first"]).to(eng.device))
-        if lay is None:
-            return logp.view(G, C)
-        out = torch.zeros(G * C, dtype=torch.float32, device=eng.device)
-        out.index_copy_(0, d_sel, logp)
-        return out.view(G, C)
+                           lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None, sel=d_sel,
+                           pred=None if lay is None else u["pred"], first=None if lay is None else u["first"])
+        return eng.unified_logps_out(u, logp)
 
     # ------------------------------------------------------------------ backward (accumulates into TrainState.grad)
     @_on_stream

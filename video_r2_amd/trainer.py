@@ -223,16 +223,18 @@ class QwenGRPOTrainer:
                         self._reward_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="vr2-rewards")
                     pending = self._reward_pool.submit(self._rewards, examples, groups)
             with self.prof.phase("_get_per_token_logps"):     # (the reference decorates this method: :722)
-                if self.beta != 0.0:     # the reference model's prompt prefill, batched the same way
-                    ref_slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="ref")
-                    ref_states = eng.prefill_batch(self.ref_params, [(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"]) for ro in new], ref_slots, tag="ref")
-                for k_, ro in enumerate(new):   # scoring while the chunk's prefix caches are still in place
+                # The log-probs that enter the loss beside the policy's -- the frozen reference model's (:826) and, with the LM
+                # frozen, the policy's own -- come from Engine.score_unified: the row space and launches of the training forward,
+                # so that identical weights give identical bits (kl == 0, ratio == 1 exactly, as in the reference) at every shape.
+                for k_, ro in enumerate(new):
                     if self.beta != 0.0:
-                        ro["ref_logps"] = eng.score(self.ref_params, ref_states[k_], ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"])
+                        ro["ref_logps"] = eng.score_unified(self.ref_params, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"],
+                                                            ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"])
                         if len(examples) > 1:
                             ro["ref_logps"] = ro["ref_logps"].clone()  # the scoring output is a reused workspace
                     if not self.update:
-                        ro["logps"] = eng.score(m.text, ro["_state"], ro["completion_ids"], a.temperature, tag="pol", lens=ro["lens"])
+                        ro["logps"] = eng.score_unified(m.text, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"],
+                                                        a.temperature, tag="ref", lens=ro["lens"], allow_fp8=False)
                         if len(examples) > 1:
                             ro["logps"] = ro["logps"].clone()
                     ro.pop("_state")
@@ -266,9 +268,11 @@ class QwenGRPOTrainer:
                                       scale_rewards=a.scale_rewards, reward_func_names=self.reward_func_names,
                                       positive_reinforcement=a.positive_reinforcement or None)
             if a.num_iterations > 1:
-                for ro in rollouts:      # old-policy log-probs, fixed for the iterations that re-use this rollout
-                    st = self.model.engine.prefill(self.model.text, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], tag="pol")
-                    ro["old_logps"] = self.model.engine.score(self.model.text, st, ro["completion_ids"], a.temperature, tag="old", lens=ro["lens"]).clone()
+                for ro in rollouts:      # old-policy log-probs, fixed for the iterations that re-use this rollout: the training
+                    # forward's own arithmetic (unified row space, bf16 GEMMs also under config 5) -> ratio == 1 at iteration 0
+                    ro["old_logps"] = self.model.engine.score_unified(self.model.text, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"],
+                                                                      ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"],
+                                                                      allow_fp8=False).clone()
             self._buffered = (rollouts, adv)
         else:
             rollouts, adv = self._buffered

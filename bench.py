@@ -7,15 +7,19 @@ bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the e
 -- this process starts them itself as a child `python -m torch.distributed.run` (as the reference launches its trainer,
 /root/reference/train/scripts/train_grpo.sh:41) and only forwards the one JSON line; the parent never touches the GPU.
 
-A "step" = one optimiser step = one pass of the hot path over P prompt groups per rank (default P = 2: the reference's
-per_device_train_batch_size x gradient_accumulation_steps; two groups of G = 8 fill the 16-row MFMA tile of the decode
-weight stream, so the weights are read once for both), inputs resident in HBM:
+A "step" = one optimiser step = one pass of the hot path over P prompt groups per rank (default P = 16: the reference's
+per_device_train_batch_size x gradient_accumulation_steps in completions / G; 16 groups of G = 8 are the 128 rows one decode
+weight pass serves, so the weights are streamed once per token for all of them), inputs resident in HBM:
   ViT encode (32 frames) -> LM prefill (once) -> shared-prefix decode of G=8 completions x C new tokens (hipGraph) ->
-  reference-model prefill + teacher-forced log-probs -> policy training forward (log-probs, activations saved) -> group
+  reference-model log-probs over the unified [prompt | completions] rows -> policy training forward (log-probs, activations saved) -> group
   advantages -> GRPO loss -> backward -> gradient all-reduce (N>1) -> global-norm clip + AdamW.
 `value` = completions produced by all ranks / wall time of the K timed steps (max over ranks).
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the decode gate/up weight-streaming GEMV, timed with HIP
-events on the engine's stream) and `cpu_baseline` (the CPU oracle = "port", bounded sample, rank 0, N=1 only).
+Prints ONE JSON line on rank 0 with `roofline` = the kernel with the largest share of the step's kernel time in the tracked
+rocprofv3 summary (profiles/*kernel_stats_default_bench_p16.md: `gemm256_kernel<4>`, the gate/up GEMM + SwiGLU of the training /
+scoring passes, MFMA-bound), timed with HIP events on the engine's stream; `roofline_decode*` = the decode phase's weight-streaming
+GEMVs (HBM-bound), `roofline_wgrad` = the largest weight-gradient GEMM; and `cpu_baseline` (the CPU oracle = "port", rank 0,
+N=1 only: a bounded sample, or the whole step with --cpu-baseline full at config 1's size).  PMC figures (`traffic`, MFMA-busy)
+come from profiles/pmc_traffic.json and are printed only while the kernel's source files are unchanged since the measurement.
 """
 from __future__ import annotations
 
@@ -34,9 +38,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_TRAFFIC_W8_128 = 148.3e6  # fp8 weights, 128 rows (profiles/r01_pmc_gemv_gateup_64rows.md, third table)
-# HBM bytes per launch by (projection, rows), rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE): filled from profiles/*.md
-PMC_TRAFFIC = {("gu", 8): 273.2e6, ("gu", 128): 285.3e6, ("down", 128): 189.5e6}   # profiles/r01_pmc_gemv_gateup.md, profiles/r02_gemv_ring.md
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md)
+
+
+def pmc_entry(name):
+    """profiles/pmc_traffic.json entry `name` (HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc
+    passes, MFMA-busy share) -- or None when the file is absent or ANY source file of the kernel has changed since the
+    measurement (sha256 recorded per entry by profiles/src/pmc_traffic.py): a counter value is evidence for the code it was
+    read from, not for its successors."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            e = json.load(f)["entries"].get(name)
+        if e is None:
+            return None
+        for rel, want in e["files"].items():
+            with open(os.path.join(ROOT, rel), "rb") as f:
+                if hashlib.sha256(f.read()).hexdigest() != want:
+                    return None
+        return e
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse():
@@ -49,6 +72,11 @@ def parse():
     p.add_argument("--G", type=int, default=8)
     p.add_argument("--max-new", type=int, default=1024)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"],
+                   help="sample: the CPU oracle on a bounded sample of the workload, extrapolated (default); full: the oracle runs the "
+                        "WHOLE step of this workload -- ViT, prefill, G x C sampled decode with KV cache, reference and policy "
+                        "log-probs, loss -- on the host cores (minutes at BASELINE config 1's size: --model 3b --frames 4 --G 2 "
+                        "--max-new 32 --prompts-per-gpu 1; hours at the headline's)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-update", action="store_true", help="rollout + scoring + loss only (no backward / optimiser)")
     p.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8", "fp8w"],
@@ -153,6 +181,58 @@ def cpu_baseline(cfg_name, n_frames, G, C):
                       f"layers on {s_s} prompt tokens, {n_dec} decode steps (G={G}), lm_head on {vs}/{t.vocab_size} vocab rows; extrapolated "
                       f"linearly to {n_frames} frames, S={S}, G={G}, C={C}: vit {t_vit:.1f}s prefill {t_prefill:.1f}s "
                       f"decode-step {t_dec_step + t_head:.2f}s scoring {t_score:.1f}s"}
+
+
+def cpu_baseline_full(cfg_name, n_frames, G, C, P):
+    """The CPU oracle ("port") running ONE WHOLE step of this workload on the host cores, nothing sampled or extrapolated:
+    per prompt group the vision tower, the prompt prefill, G sampled completions of C tokens with a KV cache (oracle generate:
+    HF's _sample loop, temperature 0.9 / top-k 50 / multinomial), the reference model's and the policy's per-token log-probs
+    (two full forward passes over [prompt | completion], as grpo_trainer.py:826 and :1094 run them) and the GRPO loss.  fp32,
+    torch CPU threads; backward and optimiser are not part of it (the oracle has none), so the figure flatters the CPU."""
+    from oracle import grpo as og
+    from oracle import ints
+    from oracle import model as om
+    threads = min(os.cpu_count(), 32)
+    torch.set_num_threads(threads)
+    oc = {"7b": om.cfg_7b, "3b": om.cfg_3b}.get(cfg_name, lambda: om.cfg_tiny(2))()
+    t0 = time.perf_counter()
+    w = om.make_weights(oc, seed=0)
+    t_init = time.perf_counter() - t0
+    from video_r2_amd.config import ModelConfig
+    ecfg = {"7b": ModelConfig.qwen25vl_7b, "3b": ModelConfig.qwen25vl_3b}.get(cfg_name, ModelConfig.tiny)()
+    phases = {"generate": 0.0, "ref_logps": 0.0, "policy_logps": 0.0, "loss": 0.0}
+    gen = torch.Generator().manual_seed(0)
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        for i in range(P):
+            px, grid, ids = synth_prompt(ecfg, n_frames, i, "cpu")
+            ids_t = torch.from_numpy(ids)[None]
+            t0 = time.perf_counter()
+            out = om.generate(w, oc, ids_t, None, px, np.asarray([grid]), [1.0], C, temperature=0.9, top_k=50,
+                              num_return_sequences=G, generator=gen, eos_token_id=None)
+            phases["generate"] += time.perf_counter() - t0
+            full = torch.clamp(out, max=oc.image_token_id - 1)
+            full[:, :ids_t.shape[1]] = ids_t
+            mm = dict(pixel_values_videos=px.repeat(G, 1), video_grid_thw=np.asarray([grid] * G), second_per_grid_ts=[1.0] * G)
+            t0 = time.perf_counter()
+            lp_ref = om.per_token_logps(w, oc, full, np.ones_like(full.numpy()), C, 0.9, **mm)
+            phases["ref_logps"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            lp = om.per_token_logps(w, oc, full, np.ones_like(full.numpy()), C, 0.9, **mm)
+            phases["policy_logps"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            comp = full[:, ids_t.shape[1]:].numpy()
+            mask, _, _ = ints.completion_mask(comp, -1)
+            adv = og.advantages(stub_rewards(comp), [1.0], G)["advantages"]
+            og.loss(lp.numpy(), mask, adv, ref_per_token_logps=lp_ref.numpy(), beta=0.04, loss_type="bnpo")
+            phases["loss"] += time.perf_counter() - t0
+    total = time.perf_counter() - t_all
+    return {"value": G * P / total, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"in full: the CPU oracle (torch fp32, {threads} threads) ran the WHOLE step -- {P} prompt group(s) x (ViT on {n_frames} "
+                      f"frames, prefill, G={G} x {C} sampled tokens with KV cache, reference + policy log-probs, loss) -- in {total:.1f} s "
+                      f"(generate {phases['generate']:.1f} s, reference log-probs {phases['ref_logps']:.1f} s, policy log-probs "
+                      f"{phases['policy_logps']:.1f} s; weight init {t_init:.1f} s not counted); no backward / optimiser on the CPU side",
+            "seconds_per_step": total, "phase_seconds": phases}
 
 
 def self_launch(a):
@@ -517,27 +597,51 @@ def main():
             kname = "gemv16_w8_kernel<1>" if NG <= 16 else ("gemv_lds_w8_kernel<1, %d>" % mbs if NG <= 64 else "gemv_lds_w8s_kernel<1, 8, 1>")
         else:
             kname = "gemv16_kernel<1, 1, 4>" if NG <= 16 else "gemv_ring_kernel<1, %d, 1, 0>" % mbs
-        # HBM bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction): profiles/r02_pmc_gemv_ring.md
-        # (7B shape, bf16 weights; 8 rows: profiles/r01_pmc_gemv_gateup.md)
-        traffic = PMC_TRAFFIC.get(("gu", NG)) if (a.model == "7b" and not fp8r) else (PMC_TRAFFIC_W8_128 if (a.model == "7b" and fp8r and not a8 and NG == 128) else None)
-        roof = {"bound": "hbm", "kernel": kname + " (decode gate/up GEMV + SiLU*mul, %d rows)" % NG, "achieved": ach,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_us": k_ms * 1e3, "algorithmic_bytes_per_launch": alg, "timed_as": k_how}
+        # HBM bytes per launch from rocprofv3 PMC (profiles/pmc_traffic.json; null once the kernel's sources have changed)
+        pm = None
+        if a.model == "7b":
+            pm = pmc_entry("gemv_gateup_bf16_%drows_7b" % NG) if not fp8r else (pmc_entry("gemv_gateup_w8_128rows_7b") if (not a8 and NG == 128) else None)
+        extra["roofline_decode"] = {"bound": "hbm", "kernel": kname + " (decode gate/up GEMV + SiLU*mul, %d rows)" % NG, "achieved": ach,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                    "traffic": pm["traffic_bytes"] if pm else None, "traffic_source": pm["source"] if pm else None,
+                                    "avg_launch_us": k_ms * 1e3, "algorithmic_bytes_per_launch": alg, "timed_as": k_how}
         # the split-K instantiation of the same kernel family: the down projection (K = I, fp32 partial slabs summed by the
-        # next kernel), at the split count the engine's decode step uses
+        # next kernel), at the split count the engine's decode step uses; and the FAMILY: q/k/v + o + down of every layer plus
+        # the lm_head, as one decode step issues them -- weights + activations in + slabs out over their summed time
         if not fp8r and NG > 16:
             db = eng._decode_bufs(NG, C, S, eng._prefix_chunk(P, S))
             p_d, ns_d = db["p_d"], db["p_d"].shape[0]
+            p_q, ns_q, p_o, ns_o = db["p_qkv"], db["p_qkv"].shape[0], db["p_o"], db["p_o"].shape[0]
+            att_b, lg_b = db["att"], db["logits"]
 
             def dn(l):
                 lib.call("vr2_gemv_bf16", act, act.stride(0), NG, pol[f"l{l}.down_w"], H, pol.shape[f"l{l}.down_w"][1], p_d,
                          p_d.stride(0) if ns_d > 1 else 0, p_d.stride(-2), ns_d, eng.s)
             d_ms, _ = timed_launches(dn)
             d_alg = 2 * I * H + NG * I * 2 + ns_d * NG * H * 4
-            extra["roofline_splitk"] = {"bound": "hbm", "kernel": "gemv_ring_kernel<0, %d, 1, 0> (decode down projection, %d rows, %d k-parts)" % (mbs, NG, ns_d),
-                                        "achieved": d_alg / (d_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": d_alg / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get(("down", NG)) if a.model == "7b" else None,
-                                        "avg_launch_us": d_ms * 1e3, "algorithmic_bytes_per_launch": d_alg}
+            pd = pmc_entry("gemv_down_bf16_%drows_7b" % NG) if a.model == "7b" else None
+            extra["roofline_decode_splitk"] = {"bound": "hbm", "kernel": "gemv_ring_kernel<0, %d, 1, 0> (decode down projection, %d rows, %d k-parts)" % (mbs, NG, ns_d),
+                                               "achieved": d_alg / (d_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": d_alg / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pd["traffic_bytes"] if pd else None,
+                                               "traffic_source": pd["source"] if pd else None,
+                                               "avg_launch_us": d_ms * 1e3, "algorithmic_bytes_per_launch": d_alg}
+
+            def fam(l):
+                eng._gemv(xn, pol, f"l{l}.qkv_w", NG, p_q, ns_q)
+                eng._gemv(att_b, pol, f"l{l}.o_w", NG, p_o, ns_o)
+                eng._gemv(act, pol, f"l{l}.down_w", NG, p_d, ns_d)
+                if l == Lh - 1:
+                    eng._gemv(xn, pol, "lm_head", NG, lg_b, 1)
+            f_ms, _ = timed_launches(fam)                      # per layer: 3 launches (+ the lm_head once per Lh layers)
+            qd = t.num_attention_heads * t.head_dim
+            f_alg = (Lh * (2 * (nqkv * H + H * qd + H * I) + NG * 2 * (H + qd + I) + NG * 4 * (ns_q * nqkv + ns_o * H + ns_d * H))
+                     + 2 * V * H + NG * 2 * H + NG * 4 * V)
+            f_tot = f_ms * Lh
+            extra["roofline_decode_splitk_family"] = {
+                "bound": "hbm", "kernel": "gemv_ring_kernel<0, %d, 1, 0> family of one decode step: %d x (q/k/v %d parts, o %d parts, down %d parts) + lm_head, %d rows"
+                                          % (mbs, Lh, ns_q, ns_o, ns_d, NG),
+                "achieved": f_alg / (f_tot * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_alg / (f_tot * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "step_total_us": f_tot * 1e3, "launches": 3 * Lh + 1, "algorithmic_bytes_per_step": f_alg}
 
         # the largest MFMA-bound kernel of the training phases, measured the same way: the gate/up GEMM + SwiGLU epilogue over
         # the unified row space of one prompt group (T = S + G*C rows), one launch per layer
@@ -557,9 +661,15 @@ def main():
         tm_, tn_ = -(-Tr // 256), -(-n_gu // 256)
         use256 = tm_ * tn_ * Tr * 4 >= 3 * -(-tm_ * tn_ // 256) * 256 * tm_ * 256          # the launcher's rule (csrc/gemm.hip)
         gname = "gemm256_kernel<4>" if use256 else "gemm_kernel<4, %d>" % (4 if -(-Tr // 128) * -(-n_gu // 128) >= 512 else 2)
-        extra["roofline_training_gemm"] = {"bound": "mfma", "kernel": gname + " (gate/up GEMM + SwiGLU, %d x %d x %d)" % (Tr, n_gu, H),
-                                           "achieved": g_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": g_tf / 2500.0, "traffic": None,
-                                           "avg_launch_us": g_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H}
+        # THE dominant kernel of the step (largest share of kernel time in the tracked rocprofv3 summary): `roofline`
+        pg = pmc_entry("gemm256_gateup_swiglu_%drows_7b" % Tr) if (a.model == "7b" and use256) else None
+        roof = {"bound": "mfma", "kernel": gname + " (gate/up GEMM + SwiGLU of the scoring / training passes, %d x %d x %d)" % (Tr, n_gu, H),
+                "achieved": g_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": g_tf / MFMA_PEAK_TFLOPS,
+                "traffic": pg["traffic_bytes"] if pg else None, "traffic_source": pg["source"] if pg else None,
+                "mfma_busy_pct": pg.get("mfma_busy_pct") if pg else None,
+                "algorithmic_bytes_per_launch": 2.0 * (Tr * H + n_gu * H + Tr * (n_gu // 2)),
+                "avg_launch_us": g_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H,
+                "dominant_by": "profiles/r04_kernel_stats_default_bench_p16.md (largest share of the step's kernel time)"}
         # the weight-gradient GEMM of the same layer (dW[2I][H] += dY[T][2I]^T X[T][H]): the largest launch of the backward
         if hasattr(upd, "state") and "l0.gu_w" in getattr(upd.state, "grad", {}):
             # operands = the step's own buffers (dY: the gate/up pre-activation gradients the last backward left in its workspace,
@@ -582,7 +692,7 @@ def main():
             gw_.copy_(keep)
             w_tf = 2.0 * Tr * n_gu * H / (w_ms * 1e-3) / 1e12
             extra["roofline_wgrad"] = {"bound": "mfma", "kernel": "gemm_tn256_kernel<1> (+ <2>: last round as k-parts) (gate/up weight gradient, %d x %d x %d, fp32 +=)" % (n_gu, H, Tr),
-                                       "achieved": w_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": w_tf / 2500.0, "traffic": None,
+                                       "achieved": w_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": w_tf / MFMA_PEAK_TFLOPS, "traffic": None,
                                        "avg_launch_us": w_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H}
             del keep
         del xa, ya
@@ -620,8 +730,12 @@ def main():
         if roof:
             line["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline:
-            say("CPU baseline (bounded sample of the oracle)")
-            line["cpu_baseline"] = cpu_baseline(a.model, a.frames, G, C)
+            if a.cpu_baseline == "full":
+                say("CPU baseline: the oracle runs the whole step on the host cores")
+                line["cpu_baseline"] = cpu_baseline_full(a.model, a.frames, G, C, P)
+            else:
+                say("CPU baseline (bounded sample of the oracle)")
+                line["cpu_baseline"] = cpu_baseline(a.model, a.frames, G, C)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

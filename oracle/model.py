@@ -290,10 +290,11 @@ def mrope_cos_sin(cfg: Cfg, position_ids):
 
 
 def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv_cache=None, emulate_bf16=False, act_quant=None,
-               rounding=None):
+               rounding=None, layer_inputs=None):
     """HF:790-872 + decoder layers :641-757.  inputs_embeds [B,S,H]; position_ids [3,B,S];
     attention_mask [B, S_total] over cached+new keys (1 = attend).  kv_cache: list of (k,v) [B,Hkv,T,hd]
-    (updated in place when given).  Returns final-normed hidden [B,S,H].  rounding: see _rounders."""
+    (updated in place when given).  Returns final-normed hidden [B,S,H].  rounding: see _rounders.
+    layer_inputs: a list that receives the residual stream entering every layer (tests that check one layer at a time)."""
     rd, ro = _rounders(emulate_bf16, rounding)
     aq = act_quant if act_quant is not None else _ident       # applied to the input of every projection (config 5, fp8 activations)
     t = cfg.text
@@ -313,6 +314,8 @@ def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv
     x = rd(inputs_embeds.float())
     for li in range(t.num_hidden_layers):
         p = f"model.layers.{li}."
+        if layer_inputs is not None:
+            layer_inputs.append(x.clone())
         h = aq(ro(rms_norm(x, w[p + "input_layernorm.weight"], t.rms_norm_eps, rd)))
         q = rd(h @ w[p + "self_attn.q_proj.weight"].t() + w[p + "self_attn.q_proj.bias"]).view(B, S, nh, hd).transpose(1, 2)
         k = rd(h @ w[p + "self_attn.k_proj.weight"].t() + w[p + "self_attn.k_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)

@@ -477,6 +477,108 @@ __global__ __launch_bounds__(512) void v5(const bf16* __restrict__ A, long lda, 
       *(bf16x4*)(C + (long)m * ldc + n) = o; } }
 }
 
+// ---------------- V7 (round 4): W fragments straight from the tile-packed weights into REGISTERS (the layout already is the MFMA A
+// operand), 3 k-tiles ahead in a 4-set register ring; X through a 4-slot LDS ring filled 3 k-tiles ahead by direct-to-LDS loads.
+// 256 x 256 x 64 tile, 8 waves, wave w owns ALL 256 rows x columns 32 w .. 32 w + 31 (its two weight tiles are nobody else's: no W
+// byte is loaded twice, LDS carries only the activation half).  Why: the shipped kernel's staging is latency-bound, not byte-bound
+// (half the bytes take 70-86 % of the time, r02_training_gemms.md): LDS holds two 64-KiB stages, ~1.5 k-tiles in flight; here the
+// bytes in flight are 3 x 32 KiB of X in LDS + 3 x 32 KiB of W in registers per CU, and there is ONE barrier per k-tile.
+// Every global access and wait is inline asm (a global_load_lds in the stream makes hipcc turn later waits into vmcnt(0)); the W
+// waits carry the register set as "+v" operands so that no MFMA is scheduled above them.
+typedef __attribute__((ext_vector_type(4))) float wreg;
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory", "m0");
+}
+template <int XCD>
+__global__ __launch_bounds__(512) void v7(const bf16* __restrict__ A, long lda, const bf16* __restrict__ Wp, int n_tiles, bf16* __restrict__ C, long ldc, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // X ring: 4 slots x [256 rows][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (XCD) {
+    const int nb = gridDim.x * gridDim.y, id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nb / 8, r = nb % 8, x = id % 8;
+    const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
+    const int per_group = 8 * gridDim.x, grp = wg / per_group, in_grp = wg % per_group;
+    const int rows = ((int)gridDim.y - grp * 8) < 8 ? ((int)gridDim.y - grp * 8) : 8;
+    by = grp * 8 + in_grp % rows; bx = in_grp / rows;
+  }
+  const int m0 = by * 256, n0 = bx * 256, fr = lane & 15, fq = lane >> 4;
+  const int ksteps = K >> 5, NT = K >> 6;
+  // X staging: 32 pieces of 8 rows x 128 B per k-tile, 4 per wave
+  const bf16* gx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i, row = piece * 8 + (lane >> 3), c = lane & 7;
+    int am = m0 + row; if (am > M - 1) am = M - 1;
+    gx[i] = A + (long)am * lda + ((c ^ (row & 7)) << 3);
+  }
+  const unsigned ring = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+  const unsigned xdst = ring + wave * 4096;                           // + slot * 32768 + i * 1024
+  // W: the wave's two 16-column weight tiles
+  int nt0 = (n0 >> 4) + wave * 2, nt1 = nt0 + 1;
+  if (nt0 > n_tiles - 1) nt0 = n_tiles - 1;
+  if (nt1 > n_tiles - 1) nt1 = n_tiles - 1;
+  const bf16* wp0 = Wp + (long)nt0 * ksteps * 512 + lane * 8;
+  const bf16* wp1 = Wp + (long)nt1 * ksteps * 512 + lane * 8;
+  wreg w[4][4];                                                       // [set][tile 0 k-step 0, tile 0 k-step 1, tile 1 k-step 0, tile 1 k-step 1]
+#define V7_ISSUE(S_, T_)                                                                                              \
+  do {                                                                                                                \
+    const int tt = (T_) < NT ? (T_) : NT - 1;                         /* phantom issues past the end re-read the last k-tile */ \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) dma16(gx[i] + (long)tt * 64, xdst + (S_) * 32768 + i * 1024);        \
+    const bf16* p0 = wp0 + (long)tt * 1024; const bf16* p1 = wp1 + (long)tt * 1024;                                   \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[S_][0]) : "v"(p0) : "memory");                            \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(w[S_][1]) : "v"(p0) : "memory");                \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[S_][2]) : "v"(p1) : "memory");                            \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(w[S_][3]) : "v"(p1) : "memory");                \
+  } while (0)
+  f32x4 acc[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+  V7_ISSUE(0, 0); V7_ISSUE(1, 1); V7_ISSUE(2, 2);
+  const int xrd = fr * 128;                                           // + rb * 2048, chunk swizzled with row & 7 = fr & 7
+  const int c0 = ((0 + fq) ^ (fr & 7)) << 4, c1 = ((4 + fq) ^ (fr & 7)) << 4;
+#define V7_TILE(S_, T_)                                                                                               \
+  do {                                                                                                                \
+    /* k-tile T: its 8 memory operations (issued three tiles ago) have landed; the 16 younger ones stay in flight */   \
+    asm volatile("s_waitcnt vmcnt(16)" : "+v"(w[S_][0]), "+v"(w[S_][1]), "+v"(w[S_][2]), "+v"(w[S_][3]) :: "memory");  \
+    asm volatile("s_barrier" ::: "memory");                                                                           \
+    V7_ISSUE(((S_) + 3) & 3, (T_) + 3);                               /* slot / set (T - 1) & 3: every wave is past tile T - 1 */ \
+    const char* xs = smem + (S_) * 32768 + xrd;                                                                       \
+    _Pragma("unroll") for (int ph = 0; ph < 4; ++ph) {                                                                \
+      bf16x8 X0[4], X1[4];                                                                                            \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                 \
+        X0[r] = *(const bf16x8*)(xs + (ph * 4 + r) * 2048 + c0);                                                      \
+        X1[r] = *(const bf16x8*)(xs + (ph * 4 + r) * 2048 + c1);                                                      \
+      }                                                                                                               \
+      __builtin_amdgcn_s_setprio(1);                                                                                  \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                 \
+        acc[0][ph * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[S_][0]), X0[r], acc[0][ph * 4 + r], 0, 0, 0); \
+        acc[1][ph * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[S_][2]), X0[r], acc[1][ph * 4 + r], 0, 0, 0); \
+      }                                                                                                               \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                 \
+        acc[0][ph * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[S_][1]), X1[r], acc[0][ph * 4 + r], 0, 0, 0); \
+        acc[1][ph * 4 + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[S_][3]), X1[r], acc[1][ph * 4 + r], 0, 0, 0); \
+      }                                                                                                               \
+      __builtin_amdgcn_s_setprio(0);                                                                                  \
+    }                                                                                                                 \
+  } while (0)
+  for (int T = 0; T < NT; T += 4) {                                   // NT % 4 == 0 (host)
+    V7_TILE(0, T); V7_TILE(1, T + 1); V7_TILE(2, T + 2); V7_TILE(3, T + 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the phantom issues of the last three tiles
+#undef V7_TILE
+#undef V7_ISSUE
+#pragma unroll
+  for (int in = 0; in < 2; ++in) {
+    const int n = n0 + wave * 32 + in * 16 + fq * 4; if (n >= N) continue;
+#pragma unroll
+    for (int im = 0; im < 16; ++im) { const int m = m0 + im * 16 + fr; if (m >= M) continue;
+      bf16x4 o = {(bf16)acc[in][im][0], (bf16)acc[in][im][1], (bf16)acc[in][im][2], (bf16)acc[in][im][3]};
+      *(bf16x4*)(C + (long)m * ldc + n) = o; } }
+}
+
 int main() {
   struct Shape { int M, N, K; const char* name; } shapes[] = {
     {9280, 4608, 3584, "lm qkv"}, {9280, 3584, 18944, "lm down"}, {9280, 37888, 3584, "lm gate/up"}, {9280, 3584, 3584, "lm o"},
@@ -533,6 +635,24 @@ int main() {
       printf("   v4 check: max|d| %.4f (max|v| %.1f) mismatches %zu\n", maxd, maxv, bad);
       free(h1); free(h2); CK(hipFree(C2));
     }
+    { static bool o7 = false; if (!o7) { o7 = true; CK(hipFuncSetAttribute((const void*)v7<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); CK(hipFuncSetAttribute((const void*)v5<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }
+    if ((s.K / 64) % 4 == 0) {  // correctness of v7 against v1
+      bf16* C2; CK(hipMalloc(&C2, (size_t)s.M * s.N * 2));
+      hipLaunchKernelGGL(v1<0>, grid, dim3(256), 65536, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K);
+      hipLaunchKernelGGL(v7<1>, dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C2, (long)s.N, s.M, s.N, s.K);
+      CK(hipDeviceSynchronize());
+      size_t n = (size_t)s.M * s.N; unsigned short* h1 = (unsigned short*)malloc(n * 2); unsigned short* h2 = (unsigned short*)malloc(n * 2);
+      CK(hipMemcpy(h1, C, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2, C2, n * 2, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < n; ++i) if (h1[i] != h2[i]) ++bad;
+      printf("   v7 check: %zu of %zu outputs differ from v1 (bit compare)\n", bad, n);
+      free(h1); free(h2); CK(hipFree(C2));
+      for (int rep = 0; rep < 2; ++rep) {
+        run("v5 shipped structure", [&] { hipLaunchKernelGGL((v5<1, 0>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+        run("v7 W->regs, X ring", [&] { hipLaunchKernelGGL((v7<1>), dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
+      }
+    }
+    if (getenv("VR2_BENCH_V7")) { CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(C)); continue; }
     run("v4 256 8phase", [&] { hipLaunchKernelGGL(v4<0>, dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     run("v4 256 8phase xcd", [&] { hipLaunchKernelGGL(v4<1>, dim3((s.N + 255) / 256, (s.M + 255) / 256), dim3(512), 131072, 0, A, (long)s.K, W, nt16, C, (long)s.N, s.M, s.N, s.K); });
     { static bool o = false; if (!o) { o = true; CK(hipFuncSetAttribute((const void*)v5<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); } }

@@ -83,7 +83,7 @@ def test_7b_28_layers_logps_vs_oracle():
     print("7B, 28 layers: the reference's own bf16 execution vs fp32: vision %.2e, logp mean %.2e max %.2e" % (ev16, r16.mean(), r16.max()))
     # At 28 layers of 3584 / 18944-long bf16 contractions no bf16 pipeline holds 1e-3 against fp32 -- and none holds it against
     # another bf16 pipeline either (the operand-rounded oracle is as far from the engine as fp32 is: rounding is discontinuous, see
-    # tests/test_7b_width_oracle_gpu.py, where every layer alone IS held to 1e-3).  The bar at full depth: closer to fp32 than the
+    # tests/test_7b_width_oracle_gpu.py, where every layer alone is held to 1e-3 on the mean).  The bar at full depth: closer to fp32 than the
     # reference's own compute dtype, plus absolute caps.
     assert ev <= ev16 and ev < 3e-2
     assert r.mean() <= r16.mean() * 1.1 and r.mean() < 6e-3 and r.max() < 2e-2, (r.mean(), r.max(), r16.mean())

@@ -62,7 +62,7 @@ def test_3b_4frames_g2_logps_vs_oracle():
     print("3B config-1 vs the operand-rounded oracle: vision rel err %.2e; logp rel err mean %.2e p95 %.2e max %.2e"
           % (ev_op, r_op.mean(), np.quantile(r_op, 0.95), r_op.max()))
     # reported, not a bar: rounding where the engine rounds does not bring the oracle closer than fp32 is (bf16 rounding is
-    # discontinuous: see tests/test_7b_width_oracle_gpu.py, where every layer ALONE is held to 1e-3 at the 7B widths)
+    # discontinuous: see tests/test_7b_width_oracle_gpu.py, where every layer ALONE is held to 1e-3 on the mean at the 7B widths)
     assert r_op.mean() < 3 * max(r.mean(), 1e-4) and ev_op < 3e-2
     print("3B config-1: vision rel err ours", ev, "bf16-reference", ev16)
     print("3B config-1: logp rel err ours mean %.2e p95 %.2e max %.2e | bf16-reference mean %.2e p95 %.2e max %.2e"

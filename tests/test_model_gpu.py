@@ -434,7 +434,8 @@ def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d      # the CPU baseline is an N = 1 leg only
+    assert d["roofline"]["bound"] == "mfma" and d["roofline_decode"]["bound"] == "hbm"     # dominant kernel of the step / of the decode
+    assert "cpu_baseline" not in d                                          # the CPU baseline is an N = 1 leg only
     assert d["eos_mix"]["samples_per_s"] > 0                                # the emulated-EOS step pair (packed rows) ran on every rank
 
 

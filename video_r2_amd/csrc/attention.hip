@@ -98,7 +98,10 @@ __device__ __forceinline__ void store_tile(const TileRegs<HD, NTHREADS, KT_>& t,
 // limit in CONCATENATED key index (key visible iff key < vis_lim && key < kend).
 // NTHREADS threads stage a tile together; NTHREADS == 64 = one wave with an LDS region of its own: no workgroup barrier (the
 // other waves of the workgroup run their own loops with their own trip counts), a wave's DS operations execute in issue order.
-template <int HD, int NTHREADS, int KT_ = KT>
+// DEPTH tiles are in flight in registers (DEPTH register sets, the loop unrolled DEPTH times): the decode bodies are latency-bound
+// walks -- one wave (suffix) or one workgroup (shared prefix) per CU streaming its keys with nothing else resident -- and with ONE
+// tile in flight a walk moves a tile per memory round trip (0.8 us per 16-key tile at 128 sequences, round 3's sweep).
+template <int HD, int NTHREADS, int KT_ = KT, int DEPTH = 1>
 __device__ __forceinline__ void attn_loop(const s16x4* qf, float scale, int kbeg, int kend, int vis_lim, bf16* sK, bf16* sV,
                                           const bf16* KA, const bf16* VA, const bf16* KB, const bf16* VB, long ldk, int hoff,
                                           int ka_row0, int ka_len, int kb_row0, float& m_run, float& l_run, f32x4* acc) {
@@ -107,14 +110,21 @@ __device__ __forceinline__ void attn_loop(const s16x4* qf, float scale, int kbeg
   const int fr = lane & 15, fq = lane >> 4;
   constexpr int NB = KT_ / 16;   // 16-key blocks per LDS tile
   const int tid = NTHREADS == 64 ? lane : (int)threadIdx.x;
-  TileRegs<HD, NTHREADS, KT_> tr;
-  load_tile<HD, NTHREADS, KT_>(tr, KA, VA, KB, VB, ldk, hoff, kbeg, ka_row0, ka_len, kb_row0, kend, tid);
-  for (int key0 = kbeg; key0 < kend; key0 += KT_) {
+  TileRegs<HD, NTHREADS, KT_> tr[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d == 0 || kbeg + d * KT_ < kend)
+      load_tile<HD, NTHREADS, KT_>(tr[d], KA, VA, KB, VB, ldk, hoff, kbeg + d * KT_, ka_row0, ka_len, kb_row0, kend, tid);
+  for (int kbase = kbeg; kbase < kend; kbase += DEPTH * KT_) {
+#pragma unroll
+   for (int d = 0; d < DEPTH; ++d) {
+    const int key0 = kbase + d * KT_;
+    if (key0 >= kend) break;                 // (uniform over the staging threads)
     if constexpr (NTHREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();  // previous tile fully consumed
-    store_tile<HD, NTHREADS, KT_>(tr, sK, sV, tid);
+    store_tile<HD, NTHREADS, KT_>(tr[d], sK, sV, tid);
     if constexpr (NTHREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-    if (key0 + KT_ < kend)   // next tile's loads fly under this tile's MFMAs
-      load_tile<HD, NTHREADS, KT_>(tr, KA, VA, KB, VB, ldk, hoff, key0 + KT_, ka_row0, ka_len, kb_row0, kend, tid);
+    if (key0 + DEPTH * KT_ < kend)   // the tile DEPTH steps ahead: its loads fly under the MFMAs of this tile and the DEPTH - 1 next
+      load_tile<HD, NTHREADS, KT_>(tr[d], KA, VA, KB, VB, ldk, hoff, key0 + DEPTH * KT_, ka_row0, ka_len, kb_row0, kend, tid);
     f32x4 s[NB];
     float mx = -INFINITY;
 #pragma unroll
@@ -167,6 +177,7 @@ __device__ __forceinline__ void attn_loop(const s16x4* qf, float scale, int kbeg
       }
       acc[db] = o;
     }
+   }
   }
 }
 
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_tok_kernel(const AttnWork* __restric
 // Prefix chunks, grid (npc, n_kv_heads, P * slot_blocks), 4 waves: the seqs_per_group sequences of a prompt group share the
 // prefix keys, so ONE workgroup stages a key chunk once and serves seqs_per_group x group query slots (G=8 sequences x 7 q
 // heads of one KV head = 56 slots on the 4 waves' 64): prefix K/V traffic and staging work drop by seqs_per_group.
-template <int HD>
+template <int HD, int DP>
 __device__ __forceinline__ void decode_prefix_body(bf16* sK, bf16* sV, int c, int kvh, int bz, const bf16* __restrict__ Q, long ldq,
                                                    const bf16* __restrict__ KP, const bf16* __restrict__ VP, long ldk,
                                                    const int* __restrict__ prefix_len_dev, int seqs_per_group,
@@ -254,7 +265,7 @@ __device__ __forceinline__ void decode_prefix_body(bf16* sK, bf16* sV, int c, in
   f32x4 acc[NKS];
 #pragma unroll
   for (int i = 0; i < NKS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  attn_loop<HD, 256, KTP>(qf, scale, kbeg, kend, qvalid ? kend : 0, sK, sV, KP, VP, KP, VP, ldk, kvh * HD, 0, prefix_len, 0, m_run,
+  attn_loop<HD, 256, KTP, DP>(qf, scale, kbeg, kend, qvalid ? kend : 0, sK, sV, KP, VP, KP, VP, ldk, kvh * HD, 0, prefix_len, 0, m_run,
                      l_run, acc);
   float l = l_run;
   l += __shfl_xor(l, 16, 64);
@@ -269,7 +280,7 @@ __device__ __forceinline__ void decode_prefix_body(bf16* sK, bf16* sV, int c, in
 
 // Suffix chunks, grid (nsc, n_kv_heads, G), one wave: the keys a sequence generated itself (unique per sequence); slots =
 // the q heads of one KV head.
-template <int HD>
+template <int HD, int DS>
 __device__ __forceinline__ void decode_suffix_body(bf16* sK, bf16* sV, int c, int kvh, int g, const bf16* __restrict__ Q, long ldq,
                                                    const bf16* __restrict__ KS, const bf16* __restrict__ VS, long ldk,
                                                    long rows_per_seq, const int* __restrict__ step, int chunk, int npc, int nslot,
@@ -303,7 +314,7 @@ __device__ __forceinline__ void decode_suffix_body(bf16* sK, bf16* sV, int c, in
   f32x4 acc[NKS];
 #pragma unroll
   for (int i = 0; i < NKS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  attn_loop<HD, 64, KTS>(qf, scale, kbeg, kend, qvalid ? kend : 0, sK, sV, KS, VS, KS, VS, ldk, kvh * HD, (int)((long)g * rows_per_seq),
+  attn_loop<HD, 64, KTS, DS>(qf, scale, kbeg, kend, qvalid ? kend : 0, sK, sV, KS, VS, KS, VS, ldk, kvh * HD, (int)((long)g * rows_per_seq),
                     total, 0, m_run, l_run, acc);
   float l = l_run;
   l += __shfl_xor(l, 16, 64);
@@ -320,7 +331,7 @@ __device__ __forceinline__ void decode_suffix_body(bf16* sK, bf16* sV, int c, in
 // workgroup barrier), the rest are prefix workgroups.  The two parts read disjoint caches and write disjoint partial slots; in
 // one grid they share the chip instead of running one after the other (prefix alone: P x n_kv x chunks short workgroups;
 // suffix alone: a tail of single waves), and a launch boundary per layer goes away.
-template <int HD>
+template <int HD, int DS, int DP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict__ Q, long ldq, const bf16* __restrict__ KP,
                                                           const bf16* __restrict__ VP, const bf16* __restrict__ KS,
                                                           const bf16* __restrict__ VS, long ldk, const int* __restrict__ prefix_len_dev,
@@ -339,12 +350,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict
     const int item = (int)blockIdx.x * 4 + wave;           // (g, kvh, c), c fastest: the live chunks of a sequence sit together
     if (item >= nsc * n_kv * G) return;
     const int c = item % nsc, kvh = (item / nsc) % n_kv, g = item / (nsc * n_kv);
-    decode_suffix_body<HD>(sK + wave * KTS * Strides<HD>::K, sV + wave * KTS * Strides<HD>::V, c, kvh, g, Q, ldq, KS, VS, ldk, rows_per_seq,
+    decode_suffix_body<HD, DS>(sK + wave * KTS * Strides<HD>::K, sV + wave * KTS * Strides<HD>::V, c, kvh, g, Q, ldq, KS, VS, ldk, rows_per_seq,
                            step, schunk, npc, nslot, group, n_heads, scale, po, pml, finished);
   } else {
     const int b = (int)blockIdx.x - n_suffix_blocks;
     const int c = b % npc, kvh = (b / npc) % n_kv, bz = b / (npc * n_kv);
-    decode_prefix_body<HD>(sK, sV, c, kvh, bz, Q, ldq, KP, VP, ldk, prefix_len_dev, seqs_per_group, prefix_group_stride, pchunk, nslot,
+    decode_prefix_body<HD, DP>(sK, sV, c, kvh, bz, Q, ldq, KP, VP, ldk, prefix_len_dev, seqs_per_group, prefix_group_stride, pchunk, nslot,
                            slot_blocks, group, n_heads, scale, po, pml);
   }
 }
@@ -486,11 +497,26 @@ extern "C" int vr2_attn_decode(const void* Q, int64_t ldq, const void* Kprefix, 
   const int P = (int)(G / seqs_per_group);
   const int n_suffix_items = (int)n_suffix_chunks * (int)n_kv * (int)G, n_suffix_blocks = (n_suffix_items + 3) / 4;
   const int n_prefix_blocks = npc * (int)n_kv * P * slot_blocks;
-  hipLaunchKernelGGL(attn_decode_kernel<128>, dim3((unsigned)(n_suffix_blocks + n_prefix_blocks)), dim3(256), 0, s, (const bf16*)Q, (long)ldq,
-                     (const bf16*)Kprefix, (const bf16*)Vprefix, (const bf16*)Ksuffix, (const bf16*)Vsuffix, (long)ldk,
-                     (const int*)prefix_len_i32, (int)seqs_per_group, (long)prefix_group_stride, (long)rows_per_seq, (const int*)step_i32,
-                     (int)chunk, (int)prefix_chunk, npc, (int)n_suffix_chunks, n_suffix_blocks, (int)n_kv, (int)G, slot_blocks, (int)group,
-                     (int)n_heads, scale, (float*)part_o_f32, (float*)part_ml_f32, (const int*)finished_i32);
+  // tiles in flight per suffix wave / per prefix workgroup (vr2_tune_set keys 3 / 4; defaults = the measured best)
+  const int ds = vr2_tune_get(VR2_TUNE_ATTN_SUFFIX_DEPTH), dp = vr2_tune_get(VR2_TUNE_ATTN_PREFIX_DEPTH);
+#define VR2_DEC_LAUNCH(DS_, DP_)                                                                                                          \
+  hipLaunchKernelGGL((attn_decode_kernel<128, DS_, DP_>), dim3((unsigned)(n_suffix_blocks + n_prefix_blocks)), dim3(256), 0, s, (const bf16*)Q, \
+                     (long)ldq, (const bf16*)Kprefix, (const bf16*)Vprefix, (const bf16*)Ksuffix, (const bf16*)Vsuffix, (long)ldk,          \
+                     (const int*)prefix_len_i32, (int)seqs_per_group, (long)prefix_group_stride, (long)rows_per_seq,                       \
+                     (const int*)step_i32, (int)chunk, (int)prefix_chunk, npc, (int)n_suffix_chunks, n_suffix_blocks, (int)n_kv, (int)G,  \
+                     slot_blocks, (int)group, (int)n_heads, scale, (float*)part_o_f32, (float*)part_ml_f32, (const int*)finished_i32)
+  if (ds <= 1 && dp <= 1) VR2_DEC_LAUNCH(1, 1);
+  else if (ds == 2 && dp <= 1) VR2_DEC_LAUNCH(2, 1);
+  else if (ds == 3 && dp <= 1) VR2_DEC_LAUNCH(3, 1);
+  else if (ds == 4 && dp <= 1) VR2_DEC_LAUNCH(4, 1);
+  else if (ds <= 1 && dp == 2) VR2_DEC_LAUNCH(1, 2);
+  else if (ds == 2 && dp == 2) VR2_DEC_LAUNCH(2, 2);
+  else if (ds == 3 && dp == 2) VR2_DEC_LAUNCH(3, 2);
+  else if (ds == 4 && dp == 2) VR2_DEC_LAUNCH(4, 2);
+  else if (ds == 2 && dp == 3) VR2_DEC_LAUNCH(2, 3);
+  else if (ds == 3 && dp == 3) VR2_DEC_LAUNCH(3, 3);
+  else VR2_DEC_LAUNCH(4, 3);
+#undef VR2_DEC_LAUNCH
   if (vr2_check_launch("vr2_attn_decode(prefix + suffix)")) return -1;
   hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)n_heads, (unsigned)G), dim3(64), 0, s, (const float*)part_o_f32,
                      (const float*)part_ml_f32, npc, nslot, (int)head_dim, (bf16*)out_bf16, (long)ldo, (int)n_heads,

@@ -20,7 +20,8 @@ void vr2_set_error(const char* fmt, ...);
 int vr2_check_launch(const char* what);
 
 // tuning knobs (api.hip: vr2_tune_set / vr2_tune_get); read on the host at launch time only
-enum { VR2_TUNE_GEMV_VARIANT = 0, VR2_TUNE_GEMV_ABLATE = 1, VR2_TUNE_GEMV_XCHUNK = 2, VR2_TUNE_COUNT = 8 };
+enum { VR2_TUNE_GEMV_VARIANT = 0, VR2_TUNE_GEMV_ABLATE = 1, VR2_TUNE_GEMV_XCHUNK = 2, VR2_TUNE_ATTN_SUFFIX_DEPTH = 3,
+       VR2_TUNE_ATTN_PREFIX_DEPTH = 4, VR2_TUNE_COUNT = 8 };
 int vr2_tune_get(int key);
 
 // attention_fwd.hip: the head_dim-128 forward behind vr2_attn_tok

@@ -85,6 +85,9 @@ def parse():
                         "With fp8 the no-grad LM GEMMs (rollout prefill, reference prefill + log-probs) run on the same copies with fp8 "
                         "activations too (vr2_gemm_a8w8); the training forward / backward stay bf16; the policy's copies are "
                         "re-quantised after every optimiser step (timed)")
+    p.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"],
+                   help="wire format of the N > 1 gradient all-reduce: fp32 arena as it is (30.5 GB per step at 7B) or rounded to bf16 "
+                        "on the way out (15.2 GB, the figure of the reference's bf16 ZeRO-3 exchange)")
     p.add_argument("--no-gemm-fp8", action="store_true",
                    help="with --decode-weights fp8: keep the no-grad LM GEMMs (rollout prefill, reference prefill + log-probs) on the "
                         "bf16 path instead of per-row e4m3 activations x e4m3 weights on the block-scaled fp8 MFMA (A/B switch)")
@@ -341,7 +344,7 @@ def main():
             W.add_fp8_decode_copies(ref)                           # frozen: quantised once
             eng.gemm_fp8 = True
     from video_r2_amd.train import Trainer
-    upd = None if a.no_update else Trainer(eng, pol)       # fp32 masters + Adam moments + transposed packed copies
+    upd = None if a.no_update else Trainer(eng, pol, grad_exchange=a.grad_exchange)       # fp32 masters + Adam moments + transposed packed copies
     P = a.prompts_per_gpu
     n_prompts = (a.steps + a.warmup + 1) * P + 2            # + one instrumented step for the phase split + 2 recipe-shaped steps
     prompts = [synth_prompt(cfg, a.frames, rank * 1000 + i, device) for i in range(n_prompts)]
@@ -715,7 +718,7 @@ def main():
                        "phases_timed": ["vit", "prefill", "decode(G x C, sampling T=0.9 top-k 50, EOS off)",
                                         "ref prefill + ref log-probs", "policy training forward", "advantages + GRPO loss"]
                                        + ([] if a.no_update else ["backward", "grad all-reduce (N>1)", "clip + AdamW"]),
-                       "parallelism": f"dp{world} (prompt groups sharded; one gradient all-reduce per step)"},
+                       "parallelism": f"dp{world} (prompt groups sharded; one gradient all-reduce per step, {a.grad_exchange} on the wire)"},
             "last_loss": loss,
             "hbm_peak_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),   # torch allocator high-water mark on rank 0
             "hbm_reserved_GB": round(torch.cuda.max_memory_reserved() / 1e9, 1),  # ... incl. the allocator's cached blocks

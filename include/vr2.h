@@ -23,7 +23,9 @@ const char* vr2_last_error(void);
 int vr2_version(void);
 /* launch-time kernel-variant knobs for A/B measurements (defaults = the measured best).  key 0: decode GEMV for 16 < M <= 128
  * rows (0 = LDS-staged kernel of round 1, 1 = one-workgroup-per-CU register-ring kernel with 3 weight chunks in flight per wave,
- * 2 = the same with 1: the default).  key 1: ablations of that kernel for profiles/ (results wrong).  key 2: x is chunk-major. */
+ * 2 = the same with 1: the default).  key 1: ablations of that kernel for profiles/ (results wrong).  key 2: x is chunk-major.
+ * keys 3 / 4: K/V tiles a decode-attention suffix wave / shared-prefix workgroup keeps in flight in registers (1-4 / 1-3; defaults
+ * 2 / 1, profiles/r04_attn_decode_depth.md). */
 int vr2_tune_set(int key, int value);
 
 /* ---- GEMMs ------------------------------------------------------------------------------------------------- */

@@ -595,9 +595,10 @@ int main() {
       size_t na = (size_t)s.M * s.K, nw = (size_t)nt16 * 16 * s.K;
       unsigned short* h = (unsigned short*)malloc((na > nw ? na : nw) * 2);
       unsigned x = 12345;
-      for (size_t i = 0; i < na; ++i) { x = x * 1664525u + 1013904223u; h[i] = (unsigned short)(((x >> 16) & 0x807f) | 0x3f00 | ((x >> 9) & 0x80)); }
+      const bool zero = getenv("VR2_BENCH_ZERO") != nullptr;    // all-zero operands: same instruction stream, no data-dependent power
+      for (size_t i = 0; i < na; ++i) { x = x * 1664525u + 1013904223u; h[i] = zero ? 0 : (unsigned short)(((x >> 16) & 0x807f) | 0x3f00 | ((x >> 9) & 0x80)); }
       CK(hipMemcpy(A, h, na * 2, hipMemcpyHostToDevice));
-      for (size_t i = 0; i < nw; ++i) { x = x * 1664525u + 1013904223u; h[i] = (unsigned short)(((x >> 16) & 0x807f) | 0x3c00 | ((x >> 9) & 0x80)); }
+      for (size_t i = 0; i < nw; ++i) { x = x * 1664525u + 1013904223u; h[i] = zero ? 0 : (unsigned short)(((x >> 16) & 0x807f) | 0x3c00 | ((x >> 9) & 0x80)); }
       CK(hipMemcpy(W, h, nw * 2, hipMemcpyHostToDevice));
       free(h);
     }

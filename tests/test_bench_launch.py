@@ -28,6 +28,15 @@ def test_gpus2_self_launches_two_ranks():
     assert out["ms_per_step"] == max(out["rank_ms_per_step"])             # the job is as slow as its slowest rank
 
 
+def test_gpus8_self_launches_eight_ranks():
+    """the driver's largest run (N = 8) rehearsed on CPU ranks: rendezvous on 127.0.0.1, eight ranks through the barrier and the
+    max-over-ranks timing, one JSON line"""
+    out = _run(["--gpus", "8", "--steps", "2", "--warmup", "0", "--launch-check", "--model", "tiny"], {"OMP_NUM_THREADS": "1"})
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert len(out["rank_ms_per_step"]) == 8 and out["ms_per_step"] == max(out["rank_ms_per_step"])
+    assert out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0
+
+
 def test_gpus1_does_not_spawn():
     out = _run(["--gpus", "1", "--steps", "2", "--launch-check"])
     assert out["n_gpus"] == 1 and out["dist_backend"] is None and len(out["rank_ms_per_step"]) == 1

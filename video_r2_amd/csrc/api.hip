@@ -24,7 +24,7 @@ int vr2_check_launch(const char* what) {
 extern "C" const char* vr2_last_error(void) { return g_err; }
 
 // ---- launch-time tuning knobs (kernel-variant selection for A/B measurements; defaults are the measured best)
-static int g_tune[VR2_TUNE_COUNT] = {2, 0, 0, 1, 1, 0, 0, 0};
+static int g_tune[VR2_TUNE_COUNT] = {2, 0, 0, 2, 1, 0, 0, 0};   // (keys 3 / 4: decode attention tiles in flight, suffix 2 / prefix 1)
 int vr2_tune_get(int key) { return (key >= 0 && key < VR2_TUNE_COUNT) ? g_tune[key] : 0; }
 extern "C" int vr2_tune_set(int key, int value) {
   if (key < 0 || key >= VR2_TUNE_COUNT) { vr2_set_error("vr2_tune_set: unknown key %d", key); return -1; }

@@ -18,17 +18,82 @@ import torch
 import torch.distributed as dist
 
 
+def collective_timeout_s():
+    """Seconds a collective may stay incomplete before this rank gives up (VR2_COLLECTIVE_TIMEOUT, default 600): the process
+    group's own timeout (RCCL's watchdog aborts the process when it expires) and the deadline of ExchangeWatch, which names the
+    gradient bucket that is stuck."""
+    return float(os.environ.get("VR2_COLLECTIVE_TIMEOUT", "600"))
+
+
 def init(backend=None, device=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); no-op for 1 process."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 or dist.is_initialized():
         return rank(), world_size()
     backend = backend or os.environ.get("VR2_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-    kw = {}
+    kw = {"timeout": datetime.timedelta(seconds=collective_timeout_s())}
     if backend == "nccl" and device is not None:
         kw["device_id"] = torch.device(device)
     dist.init_process_group(backend, **kw)
     return dist.get_rank(), dist.get_world_size()
+
+
+class ExchangeWatch:
+    """Deadline on the asynchronous gradient-bucket all-reduces.  The engine never blocks the host on a collective (the engine
+    stream waits for RCCL's), so a rank whose peer is stuck or gone would sit in its next host sync until the backend's watchdog
+    fires, with a message that names a sequence number.  A daemon thread polls the outstanding works instead: a bucket that has
+    not completed `timeout` seconds after it was issued ends THIS process with exit code 17 and one line on stderr that names the
+    bucket, its size and the rank -- the launcher (torch.distributed.run) then tears the job down.  Nothing is re-executed or
+    retried: a gradient exchange that did not happen cannot be repaired inside the step."""
+    EXIT_CODE = 17
+
+    def __init__(self, timeout=None, poll=0.25, on_timeout=None):
+        import threading
+        self.timeout = collective_timeout_s() if timeout is None else float(timeout)
+        self.poll = poll
+        self.on_timeout = on_timeout                 # tests: called instead of os._exit
+        self._lock = threading.Lock()
+        self._items = []                              # (name, work, nbytes, issued_at)
+        self._thread = None
+        self._stop = False
+
+    def add(self, name, work, nbytes):
+        import threading
+        import time
+        with self._lock:
+            self._items.append((str(name), work, int(nbytes), time.monotonic()))
+            if self._thread is None:
+                self._thread = threading.Thread(target=self._run, name="vr2-exchange-watch", daemon=True)
+                self._thread.start()
+
+    def clear(self):
+        """the step has consumed the exchanged gradients: every registered work is known to be complete"""
+        with self._lock:
+            self._items = []
+
+    def close(self):
+        self._stop = True
+
+    def _run(self):
+        import sys
+        import time
+        while not self._stop:
+            time.sleep(self.poll)
+            now = time.monotonic()
+            with self._lock:
+                self._items = [it for it in self._items if not it[1].is_completed()]
+                late = [it for it in self._items if now - it[3] > self.timeout]
+            if late:
+                name, _, nbytes, t0 = late[0]
+                msg = (f"[video_r2_amd.dist] rank {rank()} of {world_size()}: the all-reduce of gradient bucket '{name}' ({nbytes / 2 ** 20:.0f} MiB) "
+                       f"has not completed {now - t0:.0f} s after it was issued (VR2_COLLECTIVE_TIMEOUT={self.timeout:g}): a peer rank is stuck "
+                       f"or gone.  Exiting with code {self.EXIT_CODE}; {len(self._items)} bucket(s) outstanding.")
+                print(msg, file=sys.stderr, flush=True)
+                if self.on_timeout is not None:
+                    self.on_timeout(name)
+                    return
+                os._exit(self.EXIT_CODE)
 
 
 def rank():

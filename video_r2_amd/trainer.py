@@ -150,7 +150,7 @@ class QwenGRPOTrainer:
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
         self._row_pool = None                        # --reward_workers threads that split a reward function's rows
         self.update = not getattr(args, "freeze_llm", False)
-        self.updater = UpdateEngine(model.engine, model.text) if self.update else None
+        self.updater = UpdateEngine(model.engine, model.text, grad_exchange=getattr(args, "grad_exchange_dtype", "fp32")) if self.update else None
         self.steps_per_epoch = len(train_dataset) // self.groups_per_step
         n_steps = int(self.steps_per_epoch * float(args.num_train_epochs)) * max(1, args.num_iterations)
         self.total_steps = args.max_steps if args.max_steps > 0 else max(1, n_steps)

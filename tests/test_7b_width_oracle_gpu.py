@@ -72,7 +72,7 @@ def test_7b_widths_4_layers_logps_and_multi_group_decode_vs_oracle():
     # by ~sqrt(d * ulp) after it, so within a few rounding points any two bf16-operand pipelines that are not bit-identical sit one
     # rounding error apart, exactly as far as each sits from fp32.  Depth-compounded log-probs therefore cannot certify 1e-3 for ANY
     # bf16 pipeline (the reference's own bf16 execution included, r16 below); what CAN be held to 1e-3 (on the mean) at these widths is every
-    # layer on its own, from identical inputs (mean 1e-3): test_7b_widths_every_layer_alone below.
+    # layer on its own, from identical inputs: test_7b_widths_every_layer_alone below (every position of layers 1-3 within 1e-3).
     assert r_op.mean() < 3 * max(r.mean(), 1e-4) and ev_op < 1e-2
     print("7B widths, 4 layers: vision rel err ours %.2e bf16-reference %.2e; logp rel err ours mean %.2e p95 %.2e max %.2e | "
           "bf16-reference mean %.2e p95 %.2e max %.2e" % (ev, ev16, r.mean(), np.quantile(r, 0.95), r.max(), r16.mean(),
@@ -105,12 +105,14 @@ def test_7b_widths_every_layer_alone():
     M-RoPE, causal GQA attention, o GEMM, SwiGLU GEMM, down GEMM, final norm, lm_head -- and its log-probs over the full vocabulary
     are compared with the oracle's for the same layer, in fp32 and with the engine's rounding points.  No compounding over depth:
     what is left is the arithmetic of one layer + head at 3584 / 18944 / 152064-long contractions.
-    Measured (round 4): mean 4-7e-4, max 2-2.6e-3 per layer -- the MEAN holds 1e-3, single positions do not, against fp32 and
-    against the operand-rounded oracle alike: seven bf16 rounding points sit between the layer's input and the logits, and a
-    rounding point turns a difference d << ulp between two pipelines into ~sqrt(d ulp), so after a few of them any two bf16-operand
-    pipelines are one rounding error apart (a random-init layer at these widths maps 1e-3 of operand noise to ~1e-2 nats of
-    log-prob).  Bit-level agreement on identical operands is what the kernel tests hold (exact-integer GEMM / GEMV / attention
-    cases in tests/test_kernels_gpu.py); the bars here are mean <= 1e-3 and max <= 4e-3 per layer."""
+    Measured (round 4): layers 1-3, whose input is a residual stream of ordinary size: max 6.1-7.6e-4 against the operand-rounded
+    oracle, 8.1-9.0e-4 against fp32 (mean 1.6-2.3e-4) -- EVERY position within north_star's 1e-3.  Layer 0, fed raw embedding rows
+    (norm ~1, an order of magnitude below what the layers add to it, so the branch outputs' rounding noise is the whole signal):
+    mean 4.4e-4 / max 2.0e-3 (fp32: 6.8e-4 / 2.6e-3) -- the mean holds, single positions do not.  Seven bf16 rounding points sit
+    between a layer's input and the logits; the operand-rounded oracle is only 1.2-1.5x closer than fp32, because a rounding point
+    turns a difference d << ulp between two pipelines into ~sqrt(d ulp): after a few of them any two bf16-operand pipelines that are
+    not bit-identical are most of a rounding error apart.  Bit-level agreement on identical operands is what the kernel tests hold
+    (exact-integer GEMM / GEMV / attention cases in tests/test_kernels_gpu.py)."""
     from video_r2_amd import weights as W
     from video_r2_amd.engine import Engine
     torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -159,7 +161,9 @@ def test_7b_widths_every_layer_alone():
         print("7B widths, layer %d alone: logp rel err vs fp32 mean %.2e max %.2e | vs the operand-rounded oracle mean %.2e max %.2e"
               % (l, r32.mean(), r32.max(), rop.mean(), rop.max()))
         worst = max(worst, rop.max())
-        assert rop.mean() <= 1e-3 and rop.max() <= 4e-3, (l, rop.mean(), rop.max())      # the north_star tolerance on the mean
-        assert r32.mean() <= 1e-3 and r32.max() <= 4e-3, (l, r32.mean(), r32.max())
+        if l >= 1:     # north_star's tolerance on EVERY position
+            assert rop.max() <= 1e-3 and r32.max() <= 1.2e-3 and r32.mean() <= 5e-4, (l, rop.max(), r32.mean(), r32.max())
+        else:          # embedding-row input: the tolerance on the mean, single positions within 3e-3
+            assert rop.mean() <= 1e-3 and rop.max() <= 3e-3 and r32.mean() <= 1e-3 and r32.max() <= 4e-3, (l, rop.max(), r32.max())
         del eng, txt1, lg
         torch.cuda.empty_cache()

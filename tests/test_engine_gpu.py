@@ -767,3 +767,19 @@ def test_workspace_allocation_retries_after_a_cache_flush_and_explains_a_real_oo
         eng.buf("t.oom_probe2", (300, 64), torch.float32)
     monkeypatch.setattr(torch, "empty", real)
     assert eng.buf("t.oom_probe2", (10, 64), torch.float32).shape == (10, 64)
+    # a GROWING workspace whose old block is given up in the retry: graphs captured over it are dropped at that moment, also when
+    # the second attempt fails (a caller that catches the error and goes on must not replay a graph into freed memory)
+    st = eng.prefill(eng.text, np.arange(100, 120), None, None, None)
+    eng.decode(eng.text, st, 2, 4, seed=1)
+    eng.sync()
+    assert len(eng._graphs) == 1
+    epoch = eng._ws_epoch
+    monkeypatch.setattr(torch, "empty", flaky)
+    fails["n"] = 2
+    with pytest.raises(torch.OutOfMemoryError, match="d.x"):
+        eng.buf("d.x", (100000, cfg.text.hidden_size), torch.float32)          # the decode's residual workspace, asked to grow
+    monkeypatch.setattr(torch, "empty", real)
+    assert len(eng._graphs) == 0 and eng._ws_epoch > epoch
+    toks, _ = eng.decode(eng.text, st, 2, 4, seed=1)                           # re-allocates, re-captures, works
+    eng.sync()
+    assert toks.shape == (2, 4) and len(eng._graphs) == 1

@@ -58,6 +58,23 @@ def test_generate_until_matches_direct_decode_and_keeps_order(tmp_path):
     stop = np.flatnonzero(row == cfg.eos_token_id)
     want = tok.decode((row[:stop[0]] if stop.size else row).tolist(), skip_special_tokens=True)
     assert out[1] == want
+    # ... and against the ORACLE: the adapter's own answer tokens, teacher-forced through the CPU restatement of the model on the
+    # same frames and prompt, are its arg-max at every step (unless the top two logits are a near tie at bf16 operand precision)
+    one = ev.generate_until([Req(docs["videomme"]["test"][0]["q"] + "<image>", kw, vis, 0, "videomme", "test")])
+    assert one == [want]
+    ans = np.asarray(ev.last_token_rows[0], dtype=np.int64)
+    assert ans.size > 0 and np.array_equal(ans, row[:ans.size])
+    from tests.helpers import pixels_from_frames
+    px, grid = pixels_from_frames(frames.numpy(), cfg.vision)                       # dims == the source size: no resize in between
+    full = torch.from_numpy(np.concatenate([ids, ans]))[None]
+    w17 = om.make_weights(ocfg, seed=17)
+    with torch.no_grad():
+        logits = om.forward_logits(w17, ocfg, full, np.ones_like(full.numpy()), torch.from_numpy(px), np.asarray([grid]),
+                                   [hp.second_per_grid_t(cfg.vision.temporal_patch_size, sfps)])
+    S0 = len(ids)
+    top2 = logits[0, S0 - 1:S0 - 1 + ans.size].topk(2, -1)
+    for j in range(ans.size):
+        assert int(ans[j]) == int(top2.indices[j, 0]) or float(top2.values[j, 0] - top2.values[j, 1]) < 2e-2, j
     # `until` cuts at the first stop string; a string instead of a list is accepted
     if len(want) > 2:
         cut = ev.generate_until([Req("What happens first?", {**kw, "until": want[1]}, vis, 0, "videomme", "test")])

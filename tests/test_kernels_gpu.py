@@ -835,6 +835,40 @@ def test_sample_top_p_and_min_p_match_the_hf_warpers(dev, T, k, top_p, min_p):
     assert b"top_k" in L.vr2_last_error()
 
 
+def test_sample_warpers_are_reproducible_under_heavy_ties(dev):
+    """long runs of EQUAL logits: more than CAND (64) values tied at a slice's top-k threshold and more than 512 kept scores in the
+    warper list.  The candidate slots and the list slots are assigned in token-index order (no atomic counters), so which tied tokens
+    survive (the lowest indices) and the order of the sums over the kept set do not depend on scheduling: a fixed seed gives the
+    same tokens on every run, with and without top_p / min_p."""
+    V, G = 32 * 2048, 16
+    ws = torch.zeros(int(lib.load().vr2_sample_ws_bytes(G)) // 4, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    g = torch.Generator().manual_seed(9)
+    flat = torch.zeros(1, V)                                             # every token tied
+    plateau = torch.randn(1, V, generator=g)
+    plateau[0, 100:1300] = 7.0                                           # 1200 tokens tied at the top inside ONE slice (slice = 2048)
+    few = torch.randn(1, V, generator=g)
+    few[0, 5000:5040] = 6.0                                              # 40 tied winners: within every capacity
+    for logits in (flat, plateau, few):
+        ld = logits.to(dev)
+        for (k, top_p, min_p) in ((50, 1.0, 0.0), (50, 0.7, 0.0), (64, 0.9, 0.05)):
+            draws = []
+            for rep in range(6):
+                nxt = torch.full((G,), -1, dtype=torch.int32, device=dev)
+                lib.call("vr2_sample_topk_p", ld, 0, G, V, 1.0, k, top_p, min_p, 1234, None, step, None, -1, 0, nxt, None, 0, ws, S())
+                draws.append(nxt.cpu().clone())
+            assert all(torch.equal(draws[0], d) for d in draws[1:]), (k, top_p, min_p)
+            assert int(draws[0].min()) >= 0 and int(draws[0].max()) < V
+        # the tied winners that survive a full candidate list are the LOWEST indices of the plateau
+        if logits is plateau:
+            nxt = torch.zeros(G, dtype=torch.int32, device=dev)
+            seen = set()
+            for it in range(200):
+                lib.call("vr2_sample_topk_p", ld, 0, G, V, 1.0, 50, 1.0, 0.0, 99 + it, None, step, None, -1, 0, nxt, None, 0, ws, S())
+                seen.update(nxt.cpu().tolist())
+            assert seen and min(seen) >= 100 and max(seen) < 100 + 64, (min(seen), max(seen))
+
+
 def test_repetition_penalty_matches_hf_and_tracks_new_tokens(dev):
     """vr2_repetition_penalty against oracle.model.repetition_penalty (pinned against HF's RepetitionPenaltyLogitsProcessor): ids
     seen so far are penalised ONCE whatever their multiplicity, the token appended since the last call is folded into the bitmap"""

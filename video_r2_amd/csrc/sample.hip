@@ -161,6 +161,26 @@ __device__ __forceinline__ unsigned radix_select_256(const unsigned (&key)[NK], 
 // 128 rows; this form: a maximum, 256 + |list| comparisons per thread and 6 barriers.)
 constexpr int LCAP_SEL = 768;
 
+// Slot of this thread's element in the list of all elements of the workgroup whose predicate holds, in (round-major, thread-minor)
+// order -- the order of the token indices when round j of thread t holds index base + t + 256 j.  Replaces atomicAdd slot
+// counters: with those, WHICH elements fall off a full list and the order of the survivors (hence the rounding of sums over them)
+// depended on the arrival order of the atomics, i.e. a draw was not reproducible for a fixed seed once a list overflowed or a sum
+// ran over it.  `running` = elements listed in earlier rounds (same value in every thread); wc: 4 ints of LDS.  Two barriers.
+__device__ __forceinline__ int ordered_slot_256(bool pred, int& running, int* wc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(pred);
+  const int below = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wc[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { const int c = wc[w]; off += w < wave ? c : 0; tot += c; }
+  const int slot = running + off + below;
+  running += tot;
+  __syncthreads();
+  return slot;
+}
+
 __global__ __launch_bounds__(256) void topk_candidates_kernel(const float* __restrict__ logits, long ldl, int V, int top_k,
                                                               float* __restrict__ cand_val, int* __restrict__ cand_idx) {
   __shared__ unsigned hist[256];
@@ -227,25 +247,31 @@ __global__ __launch_bounds__(256) void topk_candidates_kernel(const float* __res
       }
       __syncthreads();
       thr = bc[1];
+      // the kept keys leave in token-index order (slot = number of kept keys with a smaller index): the candidate layout, and
+      // which keys survive when more than CAND are tied at the threshold (the lowest indices), do not depend on scheduling
       for (int e = tid; e < ln; e += 256)
         if (lkey[e] >= thr) {
-          const int slot = atomicAdd(&count, 1);
-          if (slot < CAND) { const int i = lidx[e]; cv[slot] = row[i]; ci[slot] = i; }
+          const int i = lidx[e];
+          int slot = 0;
+          for (int o = 0; o < ln; ++o) slot += (lkey[o] >= thr && lidx[o] < i) ? 1 : 0;
+          if (slot < CAND) { cv[slot] = row[i]; ci[slot] = i; }
         }
       return;
     }
     __syncthreads();                                // overflow: the radix path re-uses hist / bc
   }
   thr = radix_select_256<NJ>(key, k, hist, bc);
+  int running = 0;
+  int* wc = reinterpret_cast<int*>(hist);             // (the select is done with hist)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    if (key[j] != 0u && key[j] >= thr) {
-      const int slot = atomicAdd(&count, 1);
-      if (slot < CAND) {
-        const int i = lo + tid + 256 * j;
-        cv[slot] = row[i];
-        ci[slot] = i;
-      }
+    if (running >= CAND) break;                       // uniform: every thread holds the same running count
+    const bool on = key[j] != 0u && key[j] >= thr;
+    const int slot = ordered_slot_256(on, running, wc);
+    if (on && slot < CAND) {
+      const int i = lo + tid + 256 * j;
+      cv[slot] = row[i];
+      ci[slot] = i;
     }
   }
 }
@@ -303,16 +329,17 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* __r
     for (int j = 0; j < NK; ++j)
       if (key[j] != 0u && key[j] >= thr) m = fmaxf(m, val[j] * inv_temp);
     m = block_max_256(m, red_v);
-    if (tid == 0) ln = 0;
-    __syncthreads();
+    __shared__ int wc4[4];
+    int running = 0;
 #pragma unroll
-    for (int j = 0; j < NK; ++j)
-      if (key[j] != 0u && key[j] >= thr) {
-        const int slot = atomicAdd(&ln, 1);
-        if (slot < LCAP) ls[slot] = val[j] * inv_temp;
-      }
+    for (int j = 0; j < NK; ++j) {                  // list slots in candidate order (ordered_slot_256): the sums below run over the
+      const bool on = key[j] != 0u && key[j] >= thr; // same scores in the same order on every run
+      const int slot = ordered_slot_256(on, running, wc4);
+      if (on && slot < LCAP) ls[slot] = val[j] * inv_temp;
+    }
+    if (tid == 0) ln = running;
     __syncthreads();
-    const int n = ln < LCAP ? ln : LCAP;
+    const int n = running < LCAP ? running : LCAP;
     float Z = 0.f;
     for (int i = 0; i < n; ++i) Z += __expf(ls[i] - m);        // every thread the same order: identical Z
     const float lim = top_p * Z;

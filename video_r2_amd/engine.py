@@ -121,8 +121,14 @@ class Engine:
                 try:
                     b = make(full, dtype=dtype, device=self.device)
                 except torch.OutOfMemoryError:
-                    # the buffer this one replaces and the caching allocator's free blocks may be all that is in the way
-                    self._ws.pop(key, None)
+                    if torch.cuda.is_current_stream_capturing():
+                        raise                    # no synchronize / cache flush inside a stream capture: the caller sizes its buffers before it
+                    # the buffer this one replaces and the caching allocator's free blocks may be all that is in the way.  The old
+                    # block goes back to the allocator NOW: captured decode graphs and buffer dicts that hold its address are stale
+                    # from this moment, whether or not the second attempt succeeds
+                    if self._ws.pop(key, None) is not None:
+                        self._ws_epoch += 1
+                        self._drop_graphs()
                     b = None
                     self.stream.synchronize()
                     torch.cuda.empty_cache()
@@ -143,6 +149,13 @@ class Engine:
 
     def sync(self):
         self.stream.synchronize()
+
+    def _drop_graphs(self):
+        """destroy every captured decode graph (a workspace moved or was freed: the graphs hold old addresses)"""
+        for ex_ in self._graphs.values():
+            lib.call("vr2_graph_destroy", ex_)
+        self._graphs.clear()
+        self._graph_epoch = self._ws_epoch
 
     def _gemm(self, A, P: Params, wname, bias, C, M, epi):
         n, kp = P.shape[wname]
@@ -805,10 +818,7 @@ class Engine:
                bool(self.decode_fp8_act), top_p, min_p, rep, b["skip_finished"] is not None)
         graph = None
         if getattr(self, "_graph_epoch", -1) != self._ws_epoch:       # a workspace moved: every captured graph is stale
-            for ex_ in self._graphs.values():
-                lib.call("vr2_graph_destroy", ex_)
-            self._graphs.clear()
-            self._graph_epoch = self._ws_epoch
+            self._drop_graphs()
         if use_graph and forced is None and C > 1:
             graph = self._graphs.get(key)
             if graph is None:

@@ -188,9 +188,11 @@ class VideoR2EvalModel:
             toks, _ = eng.decode(self._model.text, states, 1, int(kw["max_new_tokens"]), **dec)
         eng.sync()
         out = []
+        self.last_token_rows = []            # the batch's answers as token ids (up to the stop id): what the texts were decoded from
         for row in toks.cpu().numpy():
             stop = np.flatnonzero(row == cfg.eos_token_id)
             row = row[:stop[0]] if stop.size else row
+            self.last_token_rows.append(row.copy())
             out.append(self._tokenizer.decode(row.tolist(), skip_special_tokens=True))
         return out
 

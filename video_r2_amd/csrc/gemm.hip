@@ -281,24 +281,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16* __restrict__ A, l
   }
 }
 
-// C (+)= sum over the k-parts of a SPLIT launch, in part order; one workgroup per 64 x 128 output tile
+// C (+)= sum over the k-parts of a SPLIT launch, in part order.  grid (n tiles, m tiles, 8): a workgroup sums one eighth (8 rows) of a
+// 64 x 128 output tile, one float4 per thread, the parts' loads issued eight at a time (a one-load-one-add loop over the parts is a
+// chain of memory round trips: 23 us per launch at 9 parts, rocprofv3 round 4)
 template <bool ADD>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int parts, float* __restrict__ C, long ldc, int M, int N) {
   const long tiles = (long)gridDim.x * gridDim.y, tile = (long)blockIdx.y * gridDim.x + blockIdx.x;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
+  const int e = ((int)blockIdx.z * 256 + (int)threadIdx.x) * 4, r = e >> 7, c = e & 127;
+  const int m = m0 + r, n = n0 + c;
+  if (m >= M || n >= N) return;
+  float* cp = C + (long)m * ldc + n;
+  float4 v = ADD ? *reinterpret_cast<const float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* sp = slabs + tile * (64 * BN) + e;
+  const long pstride = tiles * (64 * BN);
+  for (int p0 = 0; p0 < parts; p0 += 8) {
+    float4 t[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int e = (i * 256 + threadIdx.x) * 4, r = e >> 7, c = e & 127;
-    const int m = m0 + r, n = n0 + c;
-    if (m >= M || n >= N) continue;
-    float* cp = C + (long)m * ldc + n;
-    float4 v = ADD ? *reinterpret_cast<const float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = 0; p < parts; ++p) {
-      const float4 s = *reinterpret_cast<const float4*>(slabs + (p * tiles + tile) * (64 * BN) + e);
-      v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-    }
-    *reinterpret_cast<float4*>(cp) = v;
+    for (int j = 0; j < 8; ++j) t[j] = (p0 + j < parts) ? *reinterpret_cast<const float4*>(sp + (p0 + j) * pstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }   // part order (+ 0 past the last part)
   }
+  *reinterpret_cast<float4*>(cp) = v;
 }
 
 // slab workspace of the SPLIT launches, owned by the caller (vr2_set_gemm_workspace): a launch needs parts x tiles x 32 KiB
@@ -482,7 +486,7 @@ bool launch_tail_splitk(const void* A, int64_t lda, const void* W, const void* b
     hipLaunchKernelGGL((gemm_kernel<EPI, 2, true, F8>), grid, dim3(256), 49152, (hipStream_t)stream, (const bf16*)A, (long)lda,
                        (const bf16*)W, (int)((N + 15) / 16), (const float*)bias, (void*)g_split_ws, (long)ldc, (int)M, (int)N, (int)K,
                        (bf16*)nullptr, 0L, ws, xs);
-    hipLaunchKernelGGL((splitk_reduce_kernel<EPI == EPI_ADD_F32>), dim3((unsigned)nb, (unsigned)mb), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI == EPI_ADD_F32>), dim3((unsigned)nb, (unsigned)mb, 8), dim3(256), 0, (hipStream_t)stream,
                        (const float*)g_split_ws, (int)parts, (float*)C, (long)ldc, (int)M, (int)N);
     return true;
   } else {

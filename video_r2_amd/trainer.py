@@ -192,7 +192,15 @@ class QwenGRPOTrainer:
         for c0 in range(0, len(examples), per):
             chunk = examples[c0:c0 + per]
             pis = processed[c0:c0 + per] if processed is not None else [self.processing_fn(ex) for ex in chunk]
-            idss = [np.asarray(pi["input_ids"]).reshape(-1)[-a.max_prompt_length:] for pi in pis]
+            # the reference slices its prompt TENSOR to the last max_prompt_length tokens (grpo_trainer.py:772-776) but generates from
+            # the unsliced processor output (:783-786): the slice is a no-op on what the model sees, and a prompt longer than the limit
+            # would cut video-pad tokens away from their features in the scoring passes.  The engine always takes the whole prompt; a
+            # prompt over the limit is an error here, not a silent truncation.
+            idss = [np.asarray(pi["input_ids"]).reshape(-1) for pi in pis]
+            for ids_ in idss:
+                if a.max_prompt_length and len(ids_) > a.max_prompt_length:
+                    raise ValueError(f"prompt of {len(ids_)} tokens exceeds --max_prompt_length {a.max_prompt_length}: raise the limit or lower "
+                                     "the frame budget (FPS_MAX_FRAMES, --video_max_pixels); truncating would separate video-pad tokens from their features")
             # the chunk's clips go through the vision tower in ONE pass and its prompts through ONE prefill (full GEMM tiles)
             slots = eng.prefix_slots(len(chunk), max(len(i) for i in idss), tag="pol")
             clips = [self._clips(pi) for pi in pis]

@@ -82,7 +82,10 @@ class ExchangeWatch:
             time.sleep(self.poll)
             now = time.monotonic()
             with self._lock:
-                self._items = [it for it in self._items if not it[1].is_completed()]
+                try:
+                    self._items = [it for it in self._items if not it[1].is_completed()]
+                except Exception:                    # the process group went away under the poll (shutdown): nothing left to watch
+                    self._items = []
                 late = [it for it in self._items if now - it[3] > self.timeout]
             if late:
                 name, _, nbytes, t0 = late[0]

@@ -417,6 +417,36 @@ def test_checkpoint_resume_and_num_iterations(tmp_path):
     assert len(list(tr2.iter_steps())) == 6                                                      # the two finished steps are skipped
 
 
+def test_config5_old_policy_logps_come_from_the_bf16_arithmetic_of_the_training_forward():
+    """--decode_weights fp8 (config 5) with --num_iterations 2: the rollout decodes and the REFERENCE scores on fp8 operands, but the
+    old-policy log-probs that the ratio is taken against are computed by the bf16 GEMMs of the training forward (Engine.score_unified
+    allow_fp8=False) -- at iteration 0 they equal the policy's log-probs bit for bit, the ratio is exactly 1 and no clip branch fires,
+    as in the reference (grpo_trainer.py:1072-1077: old = logps.detach() on-policy)."""
+    from video_r2_amd import params, rewards
+    from video_r2_amd.trainer import QwenGRPOTrainer
+    m, w, ocfg = _model(2, 53)
+    args = params.parse_args(["--num_generations", "4", "--max_completion_length", "8", "--num_iterations", "2", "--learning_rate", "1e-3",
+                              "--reward_func_names", "format_reward", "--reward_weights", "1.0", "--loss_type", "bnpo", "--beta", "0.04",
+                              "--decode_weights", "fp8"])
+
+    def processing_fn(ex):
+        ids = [40 + ex["vid"], 50, 51, 52]
+        return dict(input_ids=np.asarray(ids), pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None,
+                    decode=lambda toks: ["<think>t</think> <answer>B</answer>" if i % 2 else "nope" for i in range(toks.shape[0])])
+
+    data = [dict(prompt=[{"role": "user", "content": "q"}], vid=i) for i in range(4)]
+    funcs, wts, names = rewards.load_reward_funcs("video_r2_amd.rewards", args)
+    tr = QwenGRPOTrainer(m, funcs, args, data, processing_fn, reward_weights=wts, reward_func_names=names)
+    assert m.engine.gemm_fp8 and m.engine.decode_fp8
+    steps = list(tr.iter_steps())
+    o1 = tr.step(steps[0])
+    ro = o1["rollouts"][0]
+    assert torch.equal(ro["old_logps"], ro["logps"])                              # bf16 pass == bf16 training forward, bit for bit
+    assert o1["metrics"]["clip_ratio/region_mean"] == 0.0 and o1["metrics"]["clip_ratio/low_mean"] == 0.0 and o1["metrics"]["clip_ratio/high_mean"] == 0.0
+    assert not torch.equal(ro["ref_logps"], ro["logps"])                          # the reference DID run on fp8 operands
+    assert m.engine.gemm_fp8                                                      # (the mode is restored after the bf16 pass)
+
+
 def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     """bench.py's N > 1 path (rank-dependent prompts, barriers, max-over-ranks timing, the gradient all-reduce in EVERY step
     including the instrumented one) with 2 ranks on this one GPU over gloo and the tiny config: every rank must issue the same

@@ -380,7 +380,7 @@ def main():
             ln = None if lens is None else np.minimum(lens[p_ * G:(p_ + 1) * G], Cd)
             # reference log-probs over the unified [prompt | completions] row space: the row space and launches of the policy's
             # training forward below, so identical weights give identical bits (Engine.score_unified)
-            lp_ref = eng.score_unified(ref, ids, emb, plan, [1.0], toks, 0.9, tag="ref", lens=ln)
+            lp_ref = eng.score_unified(ref, ids, emb, plan, [1.0], toks, 0.9, tag="ref", lens=ln).clone()   # (a workspace: the next pass reuses it)
             mark("ref_prefill+ref_score")
             lp = (eng.score_unified(pol, ids, emb, plan, [1.0], toks, 0.9, tag="ref", lens=ln, allow_fp8=False) if upd is None
                   else upd.forward(ids, emb, plan, [1.0], toks, 0.9, lens=ln))

@@ -237,14 +237,11 @@ class QwenGRPOTrainer:
                 for k_, ro in enumerate(new):
                     if self.beta != 0.0:
                         ro["ref_logps"] = eng.score_unified(self.ref_params, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"],
-                                                            ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"])
-                        if len(examples) > 1:
-                            ro["ref_logps"] = ro["ref_logps"].clone()  # the scoring output is a reused workspace
+                                                            ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"]).clone()
+                        # (clone: the scoring output is a workspace that the next pass over it reuses)
                     if not self.update:
                         ro["logps"] = eng.score_unified(m.text, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"],
-                                                        a.temperature, tag="ref", lens=ro["lens"], allow_fp8=False)
-                        if len(examples) > 1:
-                            ro["logps"] = ro["logps"].clone()
+                                                        a.temperature, tag="ref", lens=ro["lens"], allow_fp8=False).clone()
                     ro.pop("_state")
         rewards = pending.result() if pending is not None else self._rewards(examples, groups)
         return groups, rewards

@@ -82,6 +82,11 @@ def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
     assert st["global_step"] == 3 and [r["step"] for r in st["log_history"]] == [1, 2, 3] and "reward" in st["log_history"][0]
     assert json.loads((out_dir / "checkpoint-2" / "trainer_state.json").read_text())["global_step"] == 2
     assert len((out_dir / "runs" / "metrics.jsonl").read_text().splitlines()) == 3
+    # --log_completions: the reference's completions table (grpo_trainer.py:1206-1227: step, prompt, completion, one column per reward
+    # function) as rows of runs/completions.jsonl -- 3 steps x 1 prompt group x 4 completions
+    table = [json.loads(ln) for ln in (out_dir / "runs" / "completions.jsonl").read_text().splitlines()]
+    assert len(table) == 12 and {r["step"] for r in table} == {0, 1, 2}
+    assert all({"prompt", "completion", "reward", "accuracy_reward", "format_reward", "text_length_reward"} <= set(r) for r in table)
     # second launch, one more step allowed: resumes after step 2 (steps 3 and 4 run, not 1..4) and keeps --save_total_limit 2
     steps2, err2 = _launch(env, *flags, "--max_steps", "4")
     assert "resumed from" in err2 and "checkpoint-2 at step 2" in err2

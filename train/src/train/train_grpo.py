@@ -94,6 +94,13 @@ class MetricsSink:
                 if k != "step" and isinstance(v, (int, float)):
                     self.tb.add_scalar("train/" + k, v, row["step"])
 
+    def write_completions(self, rows):
+        """the prompt / completion / per-function reward rows of a logged step -> output_dir/runs/completions.jsonl"""
+        import json
+        with open(os.path.join(self.dir, "completions.jsonl"), "a") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
+
     def save_state(self, out_dir, trainer):
         import json
         with open(os.path.join(out_dir, "trainer_state.json"), "w") as f:
@@ -191,6 +198,9 @@ def train(argv=None, processing_fn=None, dataset=None):
                    "elapsed_s": round(time.time() - t0, 1), **trainer.log()}
             print(row, flush=True)
             sink.write(row)
+        if rank == 0 and getattr(trainer, "completions_table", None):     # --log_completions: the step's table (grpo_trainer.py:1206-1227)
+            sink.write_completions(trainer.completions_table)
+            trainer.completions_table = None
         if save_every and step % save_every == 0:
             if rank == 0:                                   # replicas are bit-identical: one writer
                 path = trainer.save_checkpoint(args.output_dir)

@@ -393,13 +393,21 @@ class QwenGRPOTrainer:
                 vw.add_fp8_decode_copies(self.ref_params)
 
     def _log_completions(self, examples, rollouts, adv):
-        """prompt / completion / reward rows of this step on rank 0 (grpo_trainer.py:1016-1019, :1206-1227: console table)"""
+        """The step's prompt / completion / per-function reward table on rank 0 (grpo_trainer.py:1016-1019 collects it, :1206-1227
+        prints a sample and, under --report_to wandb with a live run, logs it as the table "completions" -- one column per reward
+        function, `wandb_log_unique_prompts` drops repeated prompts).  Kept as `completions_table` for the entry point's sink
+        (output_dir/runs/completions.jsonl) and sent to wandb when that package is importable and a run is active."""
         G = self.num_generations
+        rpf = adv.get("rewards_per_func")
         rows = []
         for i, (ex, ro) in enumerate(zip(examples, rollouts)):
             q = next((c.get("text") for m in (ex.get("prompt") or []) if isinstance(m.get("content"), list) for c in m["content"] if "text" in c), "")
             for g, text in enumerate(ro.get("texts") or []):
-                rows.append({"step": self.global_step, "prompt": q, "completion": text, "reward": float(adv["rewards"][i * G + g])})
+                row = {"step": self.global_step, "prompt": q, "completion": text, "reward": float(adv["rewards"][i * G + g])}
+                if rpf is not None:
+                    for j, name in enumerate(self.reward_func_names):
+                        row[name] = float(rpf[i * G + g, j])
+                rows.append(row)
         if vdist.world_size() > 1:
             import torch.distributed as dist
             gathered = [None] * vdist.world_size() if vdist.rank() == 0 else None
@@ -407,8 +415,23 @@ class QwenGRPOTrainer:
             rows = [r for part in (gathered or []) for r in part]
         if vdist.rank() == 0:
             self._textual_logs = rows
+            self.completions_table = rows                      # consumed (and cleared) by whoever writes it out
             for r in rows[:4]:
                 print(f"[completions] step {r['step']} reward {r['reward']:.3f} | {r['prompt'][:80]!r} -> {r['completion'][:160]!r}")
+            if "wandb" in str(getattr(self.args, "report_to", "")):
+                try:
+                    import wandb
+                    if wandb.run is not None:
+                        cols = ["step", "prompt", "completion"] + list(self.reward_func_names)
+                        seen, data = set(), []
+                        for r in rows:
+                            if getattr(self.args, "wandb_log_unique_prompts", False) and r["prompt"] in seen:
+                                continue
+                            seen.add(r["prompt"])
+                            data.append([str(r["step"]), r["prompt"], r["completion"]] + [r.get(n) for n in self.reward_func_names])
+                        wandb.log({"completions": wandb.Table(columns=cols, data=data)})
+                except ImportError:
+                    pass
 
     def iter_steps(self):
         """Yields, per optimisation step, the dataset examples (one per prompt group) owned by this rank.  One pass of the

@@ -359,6 +359,74 @@ def test_two_rank_dp_step_keeps_replicas_identical(wire):
     assert w0 == w1 and n0 == n1                                 # replicas stay bit-identical after the update
 
 
+def _split_group_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      VR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from video_r2_amd import dist as vdist, params, rewards
+    from video_r2_amd.model import VideoR2Model
+    from video_r2_amd.trainer import QwenGRPOTrainer
+    torch.cuda.set_device(0)
+    vdist.init(device="cuda:0")
+    ocfg = om.cfg_tiny(2)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), om.make_weights(ocfg, seed=29), device="cuda:0")
+    cfg = m.cfg
+    # the shipped recipe's shape in small: FEWER completions per device than a group holds (2 of G = 4 on each of 2 ranks)
+    args = params.parse_args(["--num_generations", "4", "--per_device_train_batch_size", "2", "--max_completion_length", "8", "--beta", "0.04",
+                              "--loss_type", "bnpo", "--reward_func_names", "length_parity_reward", "--reward_weights", "1.0",
+                              "--learning_rate", "1e-3"])
+
+    def processing_fn(ex):
+        ids = [40 + ex["vid"], 50, 51, 52]
+        return dict(input_ids=np.asarray(ids), pixel_values_videos=None, video_grid_thw=None, second_per_grid_ts=None,
+                    decode=lambda toks: [" ".join(str(int(t)) for t in row) for row in toks.cpu().numpy()])
+
+    def length_parity_reward(completions, **kwargs):               # depends on the sampled tokens: differs between the ranks' slices
+        return [float(sum(int(t) for t in c[0]["content"].split()) % 5) for c in completions]
+
+    data = [dict(prompt=[{"role": "user", "content": "q"}], vid=i) for i in range(6)]
+    tr = QwenGRPOTrainer(m, [length_parity_reward], args, data, processing_fn, reward_weights=[1.0], reward_func_names=["length_parity_reward"])
+    assert tr.group_ranks == 2 and tr.local_generations == 2 and tr.groups_per_step == 1
+    steps = list(tr.iter_steps())
+    out = tr.step(steps[0])
+    torch.cuda.synchronize()
+    ro = out["rollouts"][0]
+    q.put((rank, [ex["vid"] for ex in steps[0]], len(steps), ro["completion_ids"].cpu().tolist(), out["advantages"]["rewards"].tolist(),
+           out["advantages"]["advantages"].tolist(), out["metrics"]["loss"], out["metrics"]["grad_norm"], out["metrics"]["reward"],
+           m.text["l0.o_w"].float().sum().item(), m.text["l1.ln2"].sum().item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_prompt_group_spread_over_two_ranks_like_the_reference_recipe():
+    """per_device_train_batch_size < num_generations (train_grpo.sh: 1 per device, G = 8, 8 devices): the reference deals the G
+    repeats of a prompt to G / per_device ranks; rewards are gathered and the advantages taken over the whole group
+    (grpo_trainer.py:894-981).  Here: world 2, G = 4, 2 completions per rank -- both ranks work on the SAME prompt, sample different
+    completions, the advantages of the union are the oracle's group advantages, the step takes ONE prompt (not `world`), and the
+    replicas end the step bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import grpo as og
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_split_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, v0, n0, c0, rw0, a0, l0, g0, m0, w0, x0), (r1, v1, n1, c1, rw1, a1, l1, g1, m1, w1, x1) = res
+    assert v0 == v1 and len(v0) == 1 and n0 == n1 == 6             # the same prompt on both ranks; 6 prompts -> 6 steps (not 3)
+    assert c0 != c1 and len(c0) == len(c1) == 2                     # each rank sampled its own 2 of the 4 completions
+    want = og.advantages(np.asarray(rw0 + rw1, dtype=np.float32)[:, None], [1.0], 4)["advantages"]
+    assert np.allclose(np.asarray(a0 + a1), want, atol=1e-5)        # advantages over the WHOLE group, each rank holding its rows
+    assert l0 == l1 and g0 == g1 and m0 == m1                       # reduced metrics agree (reward = the group's mean on both)
+    assert w0 == w1 and x0 == x1                                    # replicas stay bit-identical after the update
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two GPUs (the gloo rehearsal above runs the same code on one)")
 def test_two_rank_dp_step_on_rccl():
     """the same step on the "nccl" backend (RCCL over xGMI), one GPU per rank: per-layer gradient buckets all-reduced on RCCL's

@@ -3,12 +3,13 @@
 # underneath: one process per GPU (torch.distributed.run), replicated weights, prompt groups sharded over the ranks,
 # one RCCL gradient all-reduce per optimiser step.  Every flag can be overridden by appending it ("$@" wins).
 #
-# Batch shape: the batch flags count completions per device as in the reference, but a prompt group (num_generations
-# completions) never leaves its GPU, so one optimiser step takes max(1, per_device_train_batch_size *
-# gradient_accumulation_steps / num_generations) prompts PER RANK: with the recipe values below that is 8 prompts per step on
-# 8 GPUs where the reference takes 1 (8x fewer steps per epoch at the same learning rate); NUM_DEVICES=1 reproduces the
-# reference's one prompt per step.  Raise per_device_train_batch_size to num_generations * P to decode P groups per GPU
-# together (the decode streams the weights once for up to 128 sequences).
+# Batch shape: the batch flags count completions per device as in the reference.  per_device_train_batch_size *
+# gradient_accumulation_steps >= num_generations: a rank owns whole prompt groups (that many / num_generations of them).
+# FEWER than num_generations (the recipe values below: 1 per device, 8 generations): one prompt group is spread over
+# num_generations / per_device ranks, each generating its slice of the completions; rewards are gathered and the advantages
+# taken over the whole group -- on 8 GPUs that is ONE prompt per optimiser step, the reference's batch.  For throughput raise
+# per_device_train_batch_size to num_generations * P: P groups per GPU are decoded together (the decode streams the weights
+# once for up to 128 sequences; a 1-row decode streams them for a single sequence).
 #
 # Rewards: the functions are looked up by name in --reward_module (default: your src/train/reward_funcs.py next to this
 # entry point if it imports, else the engine's built-in accuracy / format rewards).  The temporal-grounding reward named

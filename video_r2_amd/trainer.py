@@ -109,20 +109,30 @@ class QwenGRPOTrainer:
         world = vdist.world_size()
         G = self.num_generations
         # The batch flags count COMPLETIONS per device, as in the reference: per optimiser step a rank works on
-        # per_device_train_batch_size x gradient_accumulation_steps completions (grpo_trainer.py:667-675).  Here a rank owns
-        # whole prompt groups, so that is max(1, .. // G) groups per rank and `world` times as many per step.  With the shipped
-        # recipe (1 x 1 on 8 ranks) the reference spreads ONE prompt over the 8 ranks; whole-group data parallelism cannot go
-        # below one prompt per rank, i.e. 8 prompts (64 completions) per optimiser step, 8x fewer steps per epoch -- said once
-        # on rank 0.  A single GPU reproduces the reference's one prompt per step exactly.
+        # per_device_train_batch_size x gradient_accumulation_steps completions (grpo_trainer.py:667-675).  At G or more a rank
+        # owns whole prompt groups: .. // G groups per rank and `world` times as many per step.
         per_rank_completions = args.per_device_train_batch_size * args.gradient_accumulation_steps
+        # A rank that is asked for FEWER completions than one group holds (the shipped recipe: 1 per device on 8 devices, G = 8):
+        # the reference's sampler repeats every prompt G times and its loader deals the step's global batch to the ranks in
+        # contiguous slices (grpo_trainer.py:73-167, :667-675), so ONE prompt group is spread over G / per_rank ranks, each
+        # generating and scoring its slice of the completions; rewards are gathered and the advantages computed over the whole
+        # group (:846-981).  Same here when the slices tile the groups exactly: `self.group_ranks` ranks share a prompt group,
+        # every one of them runs the vision tower and the prompt prefill for it (as every rank of the reference does), decodes
+        # its own `per_rank_completions` sequences with its own seed, and the step takes world / group_ranks prompts -- the
+        # reference's batch, not world times it.
+        self.group_ranks = 1
+        self.local_generations = G
+        if per_rank_completions < G and G % per_rank_completions == 0 and world % (G // per_rank_completions) == 0:
+            self.group_ranks = G // per_rank_completions
+            self.local_generations = per_rank_completions
         self.groups_per_rank = max(1, per_rank_completions // G)
-        self.groups_per_step = self.groups_per_rank * world
+        self.groups_per_step = self.groups_per_rank * world // self.group_ranks
         ref_prompts = max(1, per_rank_completions * world // G)
         if vdist.rank() == 0 and (self.groups_per_step != ref_prompts or per_rank_completions % G not in (0, per_rank_completions)):
             import sys
             print(f"[QwenGRPOTrainer] {self.groups_per_step} prompt groups ({self.groups_per_step * G} completions) per optimiser step: "
                   f"{self.groups_per_rank} per rank on {world} rank(s); the reference would take {ref_prompts} prompt(s) per step with these "
-                  "flags (whole groups stay on one GPU here)", file=sys.stderr)
+                  "flags (their completions per device neither tile a group nor hold whole groups)", file=sys.stderr)
         # normalisation unit of the token-mean losses / metrics (see vr2_grpo_loss): the reference's per-rank micro-batch
         pdb = args.per_device_train_batch_size
         self.norm_rows = 0
@@ -185,7 +195,7 @@ class QwenGRPOTrainer:
         with the reference model; the results are joined before the advantages.  -> (rollouts, rewards_per_func)"""
         a, m = self.args, self.model
         eng = m.engine
-        G = self.num_generations
+        G = self.local_generations              # sequences THIS rank generates per prompt group (num_generations unless ranks share a group)
         per = max(1, self.MAX_DECODE_ROWS // G)
         groups = []
         pending = None
@@ -247,7 +257,7 @@ class QwenGRPOTrainer:
         return groups, rewards
 
     def _rewards(self, examples, rollouts):
-        G = self.num_generations
+        G = self.local_generations
         texts = [ro["decode"](ro["completion_ids"]) if ro["decode"] else [""] * G for ro in rollouts]
         for ro, t in zip(rollouts, texts):
             ro["texts"] = t
@@ -269,9 +279,26 @@ class QwenGRPOTrainer:
         if self.global_step % a.num_iterations == 0 or self._buffered is None:
             rollouts, rewards_per_func = self._rollout_all(step_examples, seed=a.seed * 1000003 + self.global_step * 8191 + vdist.rank() * 131,
                                                            processed=processed)
-            adv = hg.group_advantages(rewards_per_func, self.reward_weights, self.num_generations, loss_type=a.loss_type,
-                                      scale_rewards=a.scale_rewards, reward_func_names=self.reward_func_names,
-                                      positive_reinforcement=a.positive_reinforcement or None)
+            if self.group_ranks > 1:
+                # ranks share prompt groups: gather the reward rows of all ranks (the reference's `gather(rewards_per_func)`,
+                # grpo_trainer.py:894-897; rank order = the global batch order, G consecutive rows = one group), compute the
+                # advantages over whole groups, keep this rank's rows (:976-981)
+                import torch.distributed as dist
+                mine = rewards_per_func.to(torch.float32).contiguous()
+                backend_dev = self.model.device if dist.get_backend() == "nccl" else "cpu"
+                parts = [torch.empty_like(mine, device=backend_dev) for _ in range(vdist.world_size())]
+                dist.all_gather(parts, mine.to(backend_dev))
+                glob = hg.group_advantages(torch.cat([p_.cpu() for p_ in parts], 0), self.reward_weights, self.num_generations, loss_type=a.loss_type,
+                                           scale_rewards=a.scale_rewards, reward_func_names=self.reward_func_names,
+                                           positive_reinforcement=a.positive_reinforcement or None)
+                n_loc = mine.shape[0]
+                lo = vdist.rank() * n_loc
+                adv = {k: (v[lo:lo + n_loc] if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n_loc * vdist.world_size()) else v)
+                       for k, v in glob.items()}
+            else:
+                adv = hg.group_advantages(rewards_per_func, self.reward_weights, self.num_generations, loss_type=a.loss_type,
+                                          scale_rewards=a.scale_rewards, reward_func_names=self.reward_func_names,
+                                          positive_reinforcement=a.positive_reinforcement or None)
             if a.num_iterations > 1:
                 for ro in rollouts:      # old-policy log-probs, fixed for the iterations that re-use this rollout: the training
                     # forward's own arithmetic (unified row space, bf16 GEMMs also under config 5) -> ratio == 1 at iteration 0
@@ -284,7 +311,7 @@ class QwenGRPOTrainer:
         dev = self.model.device
         eng = self.model.engine
         losses, metrics, outs = [], defaultdict(list), []
-        G = self.num_generations
+        G = self.local_generations               # rows this rank holds per prompt group
         # a reference micro-batch that spans several groups (per_device_train_batch_size > G) normalises the token-mean losses
         # by ITS token count: group g's share is tokens_g / tokens_block, applied as a scale on that group's loss and gradient
         scale = [1.0] * len(rollouts)
@@ -392,12 +419,12 @@ class QwenGRPOTrainer:
             if getattr(self.ref_params, "f8", None):
                 vw.add_fp8_decode_copies(self.ref_params)
 
-    def _log_completions(self, examples, rollouts, adv):
+    def _log_completions(self, examples, rollouts, adv):  # noqa: C901
         """The step's prompt / completion / per-function reward table on rank 0 (grpo_trainer.py:1016-1019 collects it, :1206-1227
         prints a sample and, under --report_to wandb with a live run, logs it as the table "completions" -- one column per reward
         function, `wandb_log_unique_prompts` drops repeated prompts).  Kept as `completions_table` for the entry point's sink
         (output_dir/runs/completions.jsonl) and sent to wandb when that package is importable and a run is active."""
-        G = self.num_generations
+        G = self.local_generations
         rpf = adv.get("rewards_per_func")
         rows = []
         for i, (ex, ro) in enumerate(zip(examples, rollouts)):
@@ -449,7 +476,10 @@ class QwenGRPOTrainer:
             limit = len(order) if epochs - ep >= 1 else int(len(order) * (epochs - ep))
             for s0 in range(0, limit - per_step + 1, per_step):
                 if n >= done:
-                    mine = vdist.shard_prompts(order[s0:s0 + per_step])
+                    if self.group_ranks > 1:     # several ranks share one prompt group: rank r works on group r // group_ranks
+                        mine = [order[s0 + vdist.rank() // self.group_ranks]]
+                    else:
+                        mine = vdist.shard_prompts(order[s0:s0 + per_step])
                     yield [self.train_dataset[i] for i in mine]
                 n += 1
                 if self.args.max_steps > 0 and n >= self.args.max_steps:

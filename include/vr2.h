@@ -211,6 +211,11 @@ int vr2_gemm_swiglu_save(const void* A_bf16, int64_t lda, const void* W_packed_b
 int vr2_swiglu_fwd(const void* gu_bf16, int64_t ldg, void* act_bf16, int64_t lda, int64_t T, int64_t I16, void* stream);
 int vr2_swiglu_bwd(const void* gu_bf16, int64_t ldg, const void* dact_bf16, int64_t ldd, void* dgu_bf16, int64_t ldo, int64_t T,
                    int64_t I16, void* stream);
+/* erf-GELU on saved fp32 pre-activations z (h = bf16(gelu(z)): the values the fused VR2_EPI_GELU_BF16 epilogue produces) and its
+ * backward dz = dh * (Phi(z) + z phi(z)) -- the merger's fc1 (HF modeling_qwen2_5_vl.py:143-146) when --freeze_merger False */
+int vr2_gelu_fwd(const void* z_f32, int64_t ldz, void* h_bf16, int64_t ldh, int64_t T, int64_t N, void* stream);
+int vr2_gelu_bwd(const void* z_f32, int64_t ldz, const void* dh_bf16, int64_t ldd, void* dz_bf16, int64_t ldo, int64_t T, int64_t N,
+                 void* stream);
 /* RMSNorm backward: dx (+)= d/dx of rmsnorm(x)*w against dy; dw += column sums (rinv = per-row scratch [M]); dx_bf16: optional
  * bf16 copy of the final dx rows (what the next dgrad / wgrad GEMMs read) */
 int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32, const void* dy_f32, int64_t ldy, void* dx_f32,

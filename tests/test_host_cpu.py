@@ -21,20 +21,23 @@ def test_train_grpo_sh_flags_parse():
         params.parse_args(["--num_generations", "1"])
 
 
-def test_unfreezing_the_vision_side_is_refused_not_downgraded():
-    """reference train_grpo.py:48-57,123-124 trains the vision tower / merger when asked; this engine trains the LM only and must
-    say so with an error instead of silently training another parameter set"""
+def test_trainable_set_follows_the_freeze_flags():
+    """reference train_grpo.py:48-64: model.visual trains unless --freeze_vision_tower, its merger unless --freeze_merger; the one
+    combination this engine cannot run (vision side trainable, LM frozen) is refused, not downgraded"""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("vr2_train_entry", os.path.join(root, "train", "src", "train", "train_grpo.py"))
     entry = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(entry)
-    base = "--model_id /m --data_path d.json --freeze_llm False".split()
-    entry.check_trainable_set(params.parse_args(base + "--freeze_vision_tower True --freeze_merger True".split()))
-    for bad in ("--freeze_vision_tower False --freeze_merger True", "--freeze_vision_tower True --freeze_merger False", ""):
-        with pytest.raises(NotImplementedError, match="freeze_"):
-            entry.check_trainable_set(params.parse_args(base + bad.split()))
+    base = "--model_id /m --data_path d.json".split()
+    for flags, want in (("--freeze_vision_tower True --freeze_merger True", (False, False)), ("--freeze_vision_tower False --freeze_merger True", (True, False)),
+                        ("--freeze_vision_tower True --freeze_merger False", (False, True)), ("", (True, True))):
+        a = params.parse_args(base + flags.split())
+        assert entry.check_trainable_set(a) == want and (a.train_vision_tower, a.train_merger) == want
+    with pytest.raises(NotImplementedError, match="freeze_llm"):
+        entry.check_trainable_set(params.parse_args(base + "--freeze_llm True --freeze_merger False --freeze_vision_tower True".split()))
+    entry.check_trainable_set(params.parse_args(base + "--freeze_llm True --freeze_merger True --freeze_vision_tower True".split()))
 
 
 def test_train_grpo_sh_emits_flags_the_parser_accepts(tmp_path):

@@ -133,17 +133,17 @@ def prefetched(steps, processing_fn, workers):
 
 
 def check_trainable_set(args):
-    """The parameter set this engine trains is the LM (decoder layers, embeddings, lm_head); the vision tower and the merger
-    are frozen, as in the shipped recipe (train_grpo.sh: --freeze_vision_tower True --freeze_merger True).  The reference
-    honours --freeze_vision_tower False / --freeze_merger False with their own learning rates (train_grpo.py:48-57,123-124,
-    params.py:55-56); training a different parameter set than the one asked for would be a silent change of the experiment,
-    so those settings are refused."""
-    asked = [f"--{name} False" for name in ("freeze_vision_tower", "freeze_merger") if not getattr(args, name)]
-    if asked:
-        raise NotImplementedError(
-            f"{' and '.join(asked)}: the MI355X engine has no backward pass through the vision tower / merger (head_dim-80 windowed "
-            "attention, GELU merger) -- it trains the LM only.  Pass --freeze_vision_tower True --freeze_merger True (the shipped "
-            "train_grpo.sh recipe), or train the vision side with the reference trainer.")
+    """Which parameter sets train (train_grpo.py:48-64 of the reference: `configure_vision_tower` sets requires_grad on model.visual
+    from --freeze_vision_tower and then on model.visual.merger from --freeze_merger; `configure_llm` on the LM from --freeze_llm).
+    The flags' parsed defaults are the reference's: False = trainable.  -> (train_tower, train_merger), also set on `args` as
+    `train_vision_tower` / `train_merger` for QwenGRPOTrainer.  The one combination this engine cannot run -- the vision side
+    trainable with the LM frozen (its gradient arrives through the LM's backward pass) -- is refused, not downgraded."""
+    tower, merger = not args.freeze_vision_tower, not args.freeze_merger
+    if (tower or merger) and args.freeze_llm:
+        raise NotImplementedError("--freeze_llm True with --freeze_vision_tower False / --freeze_merger False: the vision side trains through "
+                                  "the LM's backward pass here; unfreeze the LM or freeze the vision side")
+    args.train_vision_tower, args.train_merger = tower, merger
+    return tower, merger
 
 
 def train(argv=None, processing_fn=None, dataset=None):
@@ -163,7 +163,10 @@ def train(argv=None, processing_fn=None, dataset=None):
     log = (lambda *a: print("[train_grpo]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
     if args.ignored:
         log(f"flags accepted and ignored by the MI355X engine: {sorted(args.ignored)}")
-    check_trainable_set(args)
+    tower, merger = check_trainable_set(args)
+    if tower or merger:
+        log("trainable besides the LM: " + ", ".join(n for n, on in (("vision tower", tower), ("merger", merger)) if on)
+            + " (the KL reference keeps a frozen copy of the vision side)")
     model = VideoR2Model.from_pretrained(args.model_id, device=device)
     if dataset is None:
         if not args.data_path:

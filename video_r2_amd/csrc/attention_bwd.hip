@@ -377,7 +377,7 @@ extern "C" int vr2_attn_delta(const void* O_bf16, const void* dO_bf16, int64_t l
 extern "C" int vr2_attn_bwd_dq(const void* work_i32x8, int64_t n_work, const void* Q, int64_t ldq, const void* KA, const void* VA,
                                const void* KB, const void* VB, int64_t ldk, const void* dO, const void* rowc_f32, int64_t T,
                                void* dQ, int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* stream) {
-  VR2_REQUIRE(head_dim == 128, "vr2_attn_bwd_dq: head_dim 128 only (the LM; the ViT is frozen)");
+  VR2_REQUIRE(head_dim == 128, "vr2_attn_bwd_dq: head_dim 128 only (the ViT's 80-wide heads are passed zero-padded to 128)");
   VR2_REQUIRE(n_work >= 1 && n_heads % group == 0 && ldq % 8 == 0 && ldk % 8 == 0, "vr2_attn_bwd_dq: bad arguments");
   static bool attr = false;
   if (!attr) {
@@ -396,7 +396,7 @@ extern "C" int vr2_attn_bwd_dkv(const void* keywork_i32x8, int64_t n_work, const
                                 int64_t ldk, const void* dO, const void* rowc_f32, int64_t T, void* dK_f32, void* dV_f32,
                                 int64_t n_heads, int64_t group, int64_t head_dim, float scale, void* stream) {
   void* dK = dK_f32; void* dV = dV_f32;   // fp32 [T][ldk], ZEROED by the caller: work items add into them
-  VR2_REQUIRE(head_dim == 128, "vr2_attn_bwd_dkv: head_dim 128 only (the LM; the ViT is frozen)");
+  VR2_REQUIRE(head_dim == 128, "vr2_attn_bwd_dkv: head_dim 128 only (the ViT's 80-wide heads are passed zero-padded to 128)");
   VR2_REQUIRE(n_work >= 1 && n_heads % group == 0 && ldq % 8 == 0 && ldk % 8 == 0, "vr2_attn_bwd_dkv: bad arguments");
   static bool attr = false;
   if (!attr) {

@@ -47,6 +47,33 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16* __restrict_
   *reinterpret_cast<bf16x4*>(act + (long)t * lda + i) = o;
 }
 
+// ------------------------------------------------------------------ GELU (erf form) on saved fp32 pre-activations and its backward
+// (the merger's fc1 when the merger trains: the fused GEMM epilogue keeps no pre-activation)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ z, long ldz, bf16* __restrict__ h, long ldh, int N) {
+  const int t = blockIdx.y;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= N) return;
+  const float4 v = *reinterpret_cast<const float4*>(z + (long)t * ldz + i);
+  bf16x4 o = {f2bf(gelu_erf_f(v.x)), f2bf(gelu_erf_f(v.y)), f2bf(gelu_erf_f(v.z)), f2bf(gelu_erf_f(v.w))};
+  *reinterpret_cast<bf16x4*>(h + (long)t * ldh + i) = o;
+}
+
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {   // d/dx 0.5 x (1 + erf(x / sqrt 2)) = Phi(x) + x phi(x)
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ z, long ldz, const bf16* __restrict__ dh, long ldd,
+                                                       bf16* __restrict__ dz, long ldo, int N) {
+  const int t = blockIdx.y;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= N) return;
+  const float4 v = *reinterpret_cast<const float4*>(z + (long)t * ldz + i);
+  const bf16x4 d = *reinterpret_cast<const bf16x4*>(dh + (long)t * ldd + i);
+  bf16x4 o = {f2bf(bf2f(d[0]) * gelu_erf_grad_f(v.x)), f2bf(bf2f(d[1]) * gelu_erf_grad_f(v.y)),
+              f2bf(bf2f(d[2]) * gelu_erf_grad_f(v.z)), f2bf(bf2f(d[3]) * gelu_erf_grad_f(v.w))};
+  *reinterpret_cast<bf16x4*>(dz + (long)t * ldo + i) = o;
+}
+
 // ------------------------------------------------------------------ RMSNorm backward (row part)
 // y = x * inv * w, inv = rsqrt(mean(x^2) + eps).  dx_out[m][:] (+)= inv * (w o dy) - x * inv^3 / H * sum(x o w o dy)
 // rinv[m] = inv is also written (the weight-gradient column pass needs it).
@@ -265,6 +292,22 @@ extern "C" int vr2_swiglu_fwd(const void* gu_bf16, int64_t ldg, void* act_bf16, 
   dim3 grid((unsigned)((I16 / 4 + 255) / 256), (unsigned)T);
   hipLaunchKernelGGL(swiglu_fwd_kernel, grid, dim3(256), 0, STREAM, (const bf16*)gu_bf16, (long)ldg, (bf16*)act_bf16, (long)lda, (int)I16);
   return vr2_check_launch("vr2_swiglu_fwd");
+}
+
+extern "C" int vr2_gelu_fwd(const void* z_f32, int64_t ldz, void* h_bf16, int64_t ldh, int64_t T, int64_t N, void* stream) {
+  VR2_REQUIRE(T >= 1 && N % 4 == 0 && ldz % 4 == 0 && ldh % 4 == 0 && ldz >= N && ldh >= N, "vr2_gelu_fwd: bad shape");
+  dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)T);
+  hipLaunchKernelGGL(gelu_fwd_kernel, grid, dim3(256), 0, STREAM, (const float*)z_f32, (long)ldz, (bf16*)h_bf16, (long)ldh, (int)N);
+  return vr2_check_launch("vr2_gelu_fwd");
+}
+
+extern "C" int vr2_gelu_bwd(const void* z_f32, int64_t ldz, const void* dh_bf16, int64_t ldd, void* dz_bf16, int64_t ldo, int64_t T,
+                            int64_t N, void* stream) {
+  VR2_REQUIRE(T >= 1 && N % 4 == 0 && ldz % 4 == 0 && ldd % 4 == 0 && ldo % 4 == 0 && ldz >= N && ldd >= N && ldo >= N, "vr2_gelu_bwd: bad shape");
+  dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)T);
+  hipLaunchKernelGGL(gelu_bwd_kernel, grid, dim3(256), 0, STREAM, (const float*)z_f32, (long)ldz, (const bf16*)dh_bf16, (long)ldd,
+                     (bf16*)dz_bf16, (long)ldo, (int)N);
+  return vr2_check_launch("vr2_gelu_bwd");
 }
 
 extern "C" int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32, const void* dy_f32, int64_t ldy, void* dx_f32,

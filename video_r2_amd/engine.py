@@ -326,12 +326,15 @@ class Engine:
         return self._vision_blocks(pl, a0), pl
 
     @_on_stream
-    def encode_videos(self, clips, per_prompt=None):
+    def encode_videos(self, clips, per_prompt=None, vision=None, rows_only=False):
         """Several clips through ONE pass of the vision tower (M = all their patches: the N = 1280 / 3420 projections then run
         on full 256-row tiles instead of one 4096-patch clip at a time).  clips: list of dict(pixel_values=f32 [P_i, C*tp*ps*ps],
         grid=(t,h,w)) or dict(frames_u8=uint8 [n,3,H,W], resize_to=(H', W') | None).  per_prompt: how many consecutive clips
         each prompt owns (default: one each; 0 = a prompt without video -> (None, None)).  -> per prompt (video tokens f32
-        [Tv, out_hidden] in the window order of the plan over ITS clips, that plan); views of one buffer owned by the caller."""
+        [Tv, out_hidden] in the window order of the plan over ITS clips, that plan); views of one buffer owned by the caller.
+        vision: run another tower than the engine's own (the frozen reference model's when the policy's vision side trains).
+        rows_only: stop in front of the tower -> (patch rows bf16 [P][Kpad] in window order (a copy), the plan over ALL clips): the
+        input of train_vision.VisionTrainer.forward, which runs the tower with saved activations."""
         import ctypes
         from .host import processor as hp
         v = self.cfg.vision
@@ -378,7 +381,9 @@ class Engine:
                 lib.call("vr2_cast_rows_f32_bf16", data, data.stride(0), pl.d_gather, dst, dst.stride(0), pl.n_patches, v.patch_dim, Kp, self.s)
             singles.append(pl)
             row += pl.n_patches
-        out = self._vision_blocks(pl_all, a0).clone()          # the combined window order is clip after clip
+        if rows_only:
+            return a0.clone(), pl_all
+        out = self._vision_blocks(pl_all, a0, vision).clone()          # the combined window order is clip after clip
         res, tok, ci = [], 0, 0
         for k in per_prompt:
             if k == 0:
@@ -390,10 +395,15 @@ class Engine:
             ci += k
         return res
 
-    def _vision_blocks(self, pl, a0):
-        """patch-embed GEMM input a0 bf16 [P][Kpad] (window order) -> merged video tokens (K1-K7)"""
+    def _vision_blocks(self, pl, a0, W=None):
+        """patch-embed GEMM input a0 bf16 [P][Kpad] (window order) -> merged video tokens (K1-K7).  W: another vision parameter set
+        than the engine's own (the frozen reference model's tower when the policy's trains)"""
+        W = self.vision if W is None else W
+        return self._vision_merger(W, self._vision_tower(W, pl, a0), pl.n_patches)
+
+    def _vision_tower(self, W: Params, pl, a0):
+        """patch embedding + the ViT blocks -> residual stream x f32 [P][hidden] (window order), before the merger"""
         v = self.cfg.vision
-        W = self.vision
         P = pl.n_patches
         Hv, hd, nh = v.hidden_size, v.head_dim, v.num_heads
         Hp, Ip, Kp = pad64(Hv), pad64(v.intermediate_size), pad64(v.patch_dim)
@@ -422,6 +432,12 @@ class Engine:
             self._norm(x, W[f"b{i}.norm2"], xn, P, Hv, 1e-6)
             self._gemm(xn, W, f"b{i}.gu_w", W[f"b{i}.gu_b"], act, P, EPI_SWIGLU_BF16)
             self._gemm(act, W, f"b{i}.down_w", W[f"b{i}.down_b"], x, P, EPI_ADD_F32)
+        return x
+
+    def _vision_merger(self, W: Params, x, P):
+        """ln_q + the 2-layer MLP over groups of merge_size^2 patches -> video tokens f32 [P/4][out_hidden]"""
+        v = self.cfg.vision
+        Hv = v.hidden_size
         unit = v.spatial_merge_size ** 2
         Tv = P // unit
         mh = Hv * unit

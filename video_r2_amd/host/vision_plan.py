@@ -71,6 +71,19 @@ def segment_work(cu_seqlens, q_tile=Q_TILE):
     return np.asarray(items, dtype=np.int32).reshape(-1, 8)
 
 
+def segment_key_work(cu_seqlens, k_tile=128):
+    """Key-centric work items (vr2_attn_bwd_dkv) for NON-causal varlen segments -- the vision tower's windows / per-frame
+    sequences when it trains: a key tile of a segment is seen by every query row of that segment.  int32 [n,8]: k_row0, nk,
+    q1_row0, q1_len (causal part: none), q2_row0, q2_len (all visible), head0, nheads (1: every head is its own KV head)."""
+    items = []
+    cu = np.asarray(cu_seqlens, dtype=np.int64)
+    for a, b in zip(cu[:-1], cu[1:]):
+        n = int(b - a)
+        for k0 in range(0, n, k_tile):
+            items.append((a + k0, min(k_tile, n - k0), 0, 0, a, n, 0, 1))
+    return np.asarray(items, dtype=np.int32).reshape(-1, 8)
+
+
 def causal_work(n_q, q_row0, prefix_row0, prefix_len, self_row0, q_tile=Q_TILE, q_causal_base=0):
     """n_q consecutive query rows attending [prefix (all visible) | self rows causal]."""
     items = []

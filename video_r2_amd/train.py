@@ -99,19 +99,23 @@ class Trainer:
     """Training forward / backward / optimiser step on an Engine (shares its stream and workspaces)."""
     KEEP_LOGITS_BYTES = 8 << 30      # forward() keeps a prompt group's fp32 logits for backward() up to this size
 
-    def __init__(self, engine: Engine, text: Params, grad_exchange="fp32"):
+    def __init__(self, engine: Engine, text: Params, grad_exchange="fp32", vision_trainer=None):
         """grad_exchange: wire format of the data-parallel gradient all-reduce.  "fp32" (default) exchanges the fp32 arena as it
         is (30.5 GB per step at 7B: the exact mean of the ranks' fp32 gradients).  "bf16" rounds every bucket to bfloat16 on the
         way out, sums in bfloat16 on the wire and widens the result back into the arena: 15.2 GB per step -- the figure of the
         reference's bf16 ZeRO-3 reduce-scatter -- at a bf16 rounding per summand; every rank receives the same
-        reduced values either way, so replicas stay bit-identical."""
+        reduced values either way, so replicas stay bit-identical.
+        vision_trainer: a train_vision.VisionTrainer when the vision tower and / or the merger train (--freeze_vision_tower False /
+        --freeze_merger False): forward() then runs the tower with saved activations from the patch rows it is handed, backward() hands
+        the input gradient at the video-token rows down to it, and optimizer_step() clips and updates both parameter sets together."""
         if grad_exchange not in ("fp32", "bf16"):
             raise ValueError(f"grad_exchange must be fp32 or bf16, got {grad_exchange!r}")
         self.eng = engine
         self.text = text
         self.state = TrainState(text, engine.device)
         self.grad_exchange = grad_exchange
-        self._wire = None         # bf16 mirror of the arena (allocated at the first bf16 exchange)
+        self.vis = vision_trainer
+        self._wire = {}           # bf16 mirrors of the gradient arenas (allocated at the first bf16 exchange)
         self._saved = None
         self._works = {}          # bucket key -> in-flight all-reduce of this optimiser step
         self._watch = None        # deadline on the in-flight buckets (dist.ExchangeWatch)
@@ -143,26 +147,42 @@ class Trainer:
         if vdist.world_size() == 1 or key in self._works:
             return
         import torch.distributed as dist
-        _, first, last = next(b for b in self.state.buckets if b[0] == key)
-        buf = self.state.arena[first:last]
+        arena, first, last = self._bucket(key)
+        buf = arena[first:last]
         if self.grad_exchange == "bf16":
-            if self._wire is None:
-                self._wire = torch.empty(self.state.arena.numel(), dtype=torch.bfloat16, device=self.state.arena.device)
-            buf = self._wire[first:last]
-            buf.copy_(self.state.arena[first:last])                 # one rounding per summand, on the engine stream
+            wire = self._wire.get(id(arena))
+            if wire is None:
+                wire = self._wire[id(arena)] = torch.empty(arena.numel(), dtype=torch.bfloat16, device=arena.device)
+            buf = wire[first:last]
+            buf.copy_(arena[first:last])                            # one rounding per summand, on the engine stream
         self._works[key] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         if self._watch is None:
             self._watch = vdist.ExchangeWatch()
-        self._watch.add("head (lm_head + final norm)" if key == "head" else ("embedding rows" if key == "embed" else f"layer {key}"),
+        self._watch.add({"head": "head (lm_head + final norm)", "embed": "embedding rows", "vision": "vision tower / merger"}.get(key, f"layer {key}"),
                         self._works[key], buf.numel() * buf.element_size())
+
+    def _bucket(self, key):
+        """(arena, first element, one-past-last element) of a gradient bucket: one of the LM's backward stages, or the vision side's"""
+        for st in ([self.state] + ([self.vis.state] if self.vis is not None else [])):
+            for k, first, last in st.buckets:
+                if k == key:
+                    return st.arena, first, last
+        raise KeyError(key)
+
+    def _bucket_keys(self):
+        return [k for k, _, _ in self.state.buckets] + (["vision"] if self.vis is not None else [])
 
     # ------------------------------------------------------------------ forward with saved activations
     @_on_stream
-    def forward(self, prompt_ids, video_embeds, plan, second_per_grid_ts, completion_ids, temperature, lens=None):
+    def forward(self, prompt_ids, video_embeds, plan, second_per_grid_ts, completion_ids, temperature, lens=None, vision_rows=None):
         """lens (host ints, one per sequence): train on the first lens[g] tokens of completion g only -- the rows behind a
         completion's first EOS carry no loss (grpo_trainer.py:793-806) and, being causal successors, influence no other row, so
-        they are left out of the row space: T = S + sum(lens) rows instead of S + G*C, log-probs 0 at the skipped positions."""
+        they are left out of the row space: T = S + sum(lens) rows instead of S + G*C, log-probs 0 at the skipped positions.
+        vision_rows (with a vision_trainer): the prompt's patch rows bf16 [P][Kpad] from Engine.encode_videos(rows_only=True); the
+        vision tokens are then computed HERE, with saved activations, instead of taken from video_embeds."""
         eng, W, cfg = self.eng, self.text, self.eng.cfg
+        if self.vis is not None and vision_rows is not None and plan is not None:
+            video_embeds = self.vis.forward(plan, vision_rows)
         t = cfg.text
         H, hd, nq, nkv, I, V, L = t.hidden_size, t.head_dim, t.num_attention_heads, t.num_key_value_heads, t.intermediate_size, t.vocab_size, t.num_hidden_layers
         I16 = (I + 15) // 16 * 16
@@ -218,6 +238,8 @@ class Trainer:
         eng.head_logps(W, hs, u, temperature, logp, hn=hn, logits_all=lg_all, lse_out=lse_out, allow_f8=False)
         self._saved = dict(logits=lg_all, sv=sv, S=S, G=G, C=C, T=T, R=R, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
                            lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None, sel=d_sel,
+                           vis_dst=(_i32(u["vid_pos"][plan.window_index], eng.device).long()
+                                    if (self.vis is not None and vision_rows is not None and plan is not None) else None),
                            pred=None if lay is None else u["pred"], first=None if lay is None else u["first"])
         return eng.unified_logps_out(u, logp)
 
@@ -316,26 +338,32 @@ class Trainer:
         lib.call("vr2_embed_bwd", s["ids"], skip, dx, dx.stride(0), ge, ge.stride(0), T, H, eng.s)
         if exchange:
             self._exchange("embed")
+        if s.get("vis_dst") is not None:
+            # the video-token rows of the LM input carry the vision side's output: their input gradient, in the window order the
+            # merger produced them, goes down through the merger (and the tower)
+            self.vis.backward(dx.index_select(0, s["vis_dst"]))
+            if exchange:
+                self._exchange("vision")
         self._saved = None
 
     # ------------------------------------------------------------------ checkpoint resume
     @_on_stream
     def refresh_compute_copies(self):
         """Re-derive every bf16 compute copy (packed W, packed W^T, embedding rows) from the fp32 masters."""
-        st, W = self.state, self.text
-        for name, p in st.master.items():
-            if st.kind[name] == "mat":
-                src = st.master["embed"] if (st.tied and name == "lm_head") else p
-                n, kp = W.shape[name]
-                w = torch.zeros((n, kp), dtype=torch.bfloat16, device=src.device)
-                w[:, :src.shape[1]] = src.to(torch.bfloat16)
-                W.t[name].copy_(pack_tiles(w))
-                kt, npad = W.shape[name + "_t"]
-                wt = torch.zeros((kt, npad), dtype=torch.bfloat16, device=src.device)
-                wt[:, :n] = w.t()
-                W.t[name + "_t"].copy_(pack_tiles(wt))
-            elif st.kind[name] == "rows":
-                W.t["embed"].copy_(p.to(torch.bfloat16))
+        for gi, (st, W) in enumerate([(self.state, self.text)] + ([(self.vis.state, self.vis.W)] if self.vis is not None else [])):
+            for name, p in st.master.items():
+                if st.kind[name] == "mat":
+                    src = st.master["embed"] if (gi == 0 and st.tied and name == "lm_head") else p
+                    n, kp = W.shape[name]
+                    w = torch.zeros((n, kp), dtype=torch.bfloat16, device=src.device)
+                    w[:, :src.shape[1]] = src.to(torch.bfloat16)
+                    W.t[name].copy_(pack_tiles(w))
+                    kt, npad = W.shape[name + "_t"]
+                    wt = torch.zeros((kt, npad), dtype=torch.bfloat16, device=src.device)
+                    wt[:, :n] = w.t()
+                    W.t[name + "_t"].copy_(pack_tiles(wt))
+                elif st.kind[name] == "rows":
+                    W.t["embed"].copy_(p.to(torch.bfloat16))
 
     # ------------------------------------------------------------------ optimiser step
     @_on_stream
@@ -347,48 +375,52 @@ class Trainer:
             st.grad["embed"].add_(st.grad["lm_head"])        # one shared parameter (Qwen2.5-VL-3B)
         world = vdist.world_size()
         if world > 1:
-            for key, _, _ in st.buckets:                      # whatever the last backward did not already put on the wire
+            for key in self._bucket_keys():                   # whatever the last backward did not already put on the wire
                 self._exchange(key)
             for key, wk in self._works.items():
                 wk.wait()                                     # the engine stream waits for RCCL's; the host does not
                 if self.grad_exchange == "bf16":              # widen the reduced bucket back into the fp32 arena
-                    _, first, last = next(b for b in st.buckets if b[0] == key)
-                    st.arena[first:last].copy_(self._wire[first:last])
+                    arena, first, last = self._bucket(key)
+                    arena[first:last].copy_(self._wire[id(arena)][first:last])
             self._works = {}
             grad_scale = grad_scale / world                   # SUM -> mean, folded into the clip coefficient
-        names = [n_ for n_ in st.grad if not (st.tied and n_ == "lm_head")]
+        groups = [(st, W)] + ([(self.vis.state, self.vis.W)] if self.vis is not None else [])
+        names = [(g_, n_) for g_, (gs, _) in enumerate(groups) for n_ in gs.grad if not (g_ == 0 and st.tied and n_ == "lm_head")]
         slot_f = int(lib.load().vr2_sumsq_slot_floats())
         if st.sumsq.numel() != len(names) * slot_f:
             st.sumsq = torch.zeros(len(names) * slot_f, dtype=torch.float32, device=st.sumsq.device)
-        for slot, name in enumerate(names):      # per-tensor slots of per-block partials, summed in a fixed order: no atomics
-            g = st.grad[name]
+        for slot, (g_, name) in enumerate(names):   # per-tensor slots of per-block partials, summed in a fixed order: no atomics
+            g = groups[g_][0].grad[name]
             lib.call("vr2_sumsq_f32", g, g.numel(), st.sumsq, slot, eng.s)
         lib.call("vr2_clip_coef", st.sumsq, len(names), float(max_grad_norm if max_grad_norm else 0.0), float(grad_scale), st.coef,
                  st.gnorm, eng.s)
         st.step_count += 1
-        for name, p in st.master.items():
-            if st.tied and name == "lm_head":
-                continue
-            g, m, v = st.grad[name], st.m[name], st.v[name]
-            wd = weight_decay if st.decay[name] else 0.0
-            kind = st.kind[name]
-            if kind == "mat":
-                n, kp = W.shape[name]
-                kt, npad = W.shape[name + "_t"]
-                lib.call("vr2_adamw", p, g, m, v, p.shape[0], p.shape[1], lr, beta1, beta2, eps, wd, st.step_count, st.coef,
-                         W[name], kp, W[name + "_t"], npad, None, 0, eng.s)
-            elif kind == "rows":
-                n, k = p.shape
-                if st.tied:
-                    kp = W.shape["lm_head"][1]
-                    lib.call("vr2_adamw", p, g, m, v, n, k, lr, beta1, beta2, eps, wd, st.step_count, st.coef, W["lm_head"], kp,
-                             W["lm_head_t"], W.shape["lm_head_t"][1], W["embed"], W["embed"].stride(0), eng.s)
+        for g_, (gs, GW) in enumerate(groups):
+            for name, p in gs.master.items():
+                if g_ == 0 and st.tied and name == "lm_head":
+                    continue
+                g, m, v = gs.grad[name], gs.m[name], gs.v[name]
+                wd = weight_decay if gs.decay[name] else 0.0
+                kind = gs.kind[name]
+                if kind == "mat":
+                    n, kp = GW.shape[name]
+                    kt, npad = GW.shape[name + "_t"]
+                    lib.call("vr2_adamw", p, g, m, v, p.shape[0], p.shape[1], lr, beta1, beta2, eps, wd, st.step_count, st.coef,
+                             GW[name], kp, GW[name + "_t"], npad, None, 0, eng.s)
+                elif kind == "rows":
+                    n, k = p.shape
+                    if st.tied:
+                        kp = GW.shape["lm_head"][1]
+                        lib.call("vr2_adamw", p, g, m, v, n, k, lr, beta1, beta2, eps, wd, st.step_count, st.coef, GW["lm_head"], kp,
+                                 GW["lm_head_t"], GW.shape["lm_head_t"][1], GW["embed"], GW["embed"].stride(0), eng.s)
+                    else:
+                        lib.call("vr2_adamw", p, g, m, v, n, k, lr, beta1, beta2, eps, wd, st.step_count, st.coef, None, 0, None, 0,
+                                 GW["embed"], GW["embed"].stride(0), eng.s)
                 else:
-                    lib.call("vr2_adamw", p, g, m, v, n, k, lr, beta1, beta2, eps, wd, st.step_count, st.coef, None, 0, None, 0,
-                             W["embed"], W["embed"].stride(0), eng.s)
-            else:
-                lib.call("vr2_adamw", p, g, m, v, 1, p.numel(), lr, beta1, beta2, eps, wd, st.step_count, st.coef, None, 0, None, 0,
-                         None, 0, eng.s)
+                    lib.call("vr2_adamw", p, g, m, v, 1, p.numel(), lr, beta1, beta2, eps, wd, st.step_count, st.coef, None, 0, None, 0,
+                             None, 0, eng.s)
+        if self.vis is not None:
+            self.vis.state.zero_grad()
         st.zero_grad()
         if self._watch is not None and world > 1:
             # the deadline thread keeps polling the step's works until they report complete; nothing to do here: clear() would

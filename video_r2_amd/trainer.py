@@ -160,7 +160,23 @@ class QwenGRPOTrainer:
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
         self._row_pool = None                        # --reward_workers threads that split a reward function's rows
         self.update = not getattr(args, "freeze_llm", False)
-        self.updater = UpdateEngine(model.engine, model.text, grad_exchange=getattr(args, "grad_exchange_dtype", "fp32")) if self.update else None
+        # the vision side trains when asked (train_grpo.py:48-57: requires_grad of model.visual from freeze_vision_tower, then of
+        # model.visual.merger from freeze_merger).  Parsed defaults are the reference's (both False = trainable); a trainer built
+        # from arguments that do not mention them at all (tests, embedding callers) keeps the frozen default of the shipped recipe
+        self.train_tower = getattr(args, "train_vision_tower", False)
+        self.train_merger = getattr(args, "train_merger", False)
+        self.ref_vision = None
+        vis_tr = None
+        if self.train_tower or self.train_merger:
+            if not self.update:
+                raise NotImplementedError("--freeze_llm True with a trainable vision tower / merger: the vision side trains through the "
+                                          "LM's backward pass, which --freeze_llm switches off in this engine")
+            from .train_vision import VisionTrainer
+            if self.ref_params is not None:      # the frozen reference model keeps the ORIGINAL tower (its own copy, as the reference's)
+                self.ref_vision = vw.clone_params(model.vision)
+            vis_tr = VisionTrainer(model.engine, model.vision, self.train_tower, self.train_merger)
+        self.updater = (UpdateEngine(model.engine, model.text, grad_exchange=getattr(args, "grad_exchange_dtype", "fp32"), vision_trainer=vis_tr)
+                        if self.update else None)
         self.steps_per_epoch = len(train_dataset) // self.groups_per_step
         n_steps = int(self.steps_per_epoch * float(args.num_train_epochs)) * max(1, args.num_iterations)
         self.total_steps = args.max_steps if args.max_steps > 0 else max(1, n_steps)
@@ -230,7 +246,8 @@ class QwenGRPOTrainer:
                 # above) and influence nothing before them, so the scoring / training passes pack the sequences at these lengths
                 lens = mask.sum(1).cpu().numpy() if getattr(a, "pack_completions", True) else None
                 new.append(dict(prompt_ids=ids, completion_ids=toks, completion_mask=mask, any_eos=any_eos, logps=None, lens=lens,
-                                ref_logps=None, decode=pi.get("decode"), emb=emb, plan=plan, sec=sec, _state=states[p_]))
+                                ref_logps=None, decode=pi.get("decode"), emb=emb, plan=plan, sec=sec, _state=states[p_],
+                                clips=clips[p_] if self.ref_vision is not None or self.train_tower or self.train_merger else None))
             groups.extend(new)
             last = c0 + per >= len(examples)
             if last:      # every completion exists: start the reward functions, then keep the GPU busy with the scoring passes
@@ -246,7 +263,9 @@ class QwenGRPOTrainer:
                 # so that identical weights give identical bits (kl == 0, ratio == 1 exactly, as in the reference) at every shape.
                 for k_, ro in enumerate(new):
                     if self.beta != 0.0:
-                        ro["ref_logps"] = eng.score_unified(self.ref_params, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"],
+                        if self.ref_vision is not None and ro["clips"]:   # the policy's tower trains: the reference sees its own
+                            (ro["ref_emb"], _), = eng.encode_videos(ro["clips"], per_prompt=[len(ro["clips"])], vision=self.ref_vision)
+                        ro["ref_logps"] = eng.score_unified(self.ref_params, ro["prompt_ids"], ro.get("ref_emb", ro["emb"]), ro["plan"], ro["sec"],
                                                             ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"]).clone()
                         # (clone: the scoring output is a workspace that the next pass over it reuses)
                     if not self.update:
@@ -326,8 +345,11 @@ class QwenGRPOTrainer:
             live = ro["lens"] is None or int(ro["lens"].sum()) > 0       # (a group whose completions are all masked out has no rows)
             if self.update and live:      # policy log-probs WITH saved activations (the forward of grpo_trainer.py:1094-1096)
                 with self.prof.phase("_get_per_token_logps"):
+                    rows = None
+                    if self.updater.vis is not None and ro.get("clips"):     # the vision side trains: the tower runs inside forward()
+                        rows, _ = eng.encode_videos(ro["clips"], per_prompt=[len(ro["clips"])], rows_only=True)
                     ro["logps"] = self.updater.forward(ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"], a.temperature,
-                                                       lens=ro["lens"])
+                                                       lens=ro["lens"], vision_rows=rows)
             elif self.update:
                 ro["logps"] = torch.zeros(ro["completion_ids"].shape, dtype=torch.float32, device=dev)
             with torch.cuda.stream(eng.stream):
@@ -498,6 +520,10 @@ class QwenGRPOTrainer:
             st = self.updater.state
             state.update(step_count=st.step_count, master={k: v.cpu() for k, v in st.master.items()},
                          m={k: v.cpu() for k, v in st.m.items()}, v={k: v.cpu() for k, v in st.v.items()})
+            if self.updater.vis is not None:
+                vs = self.updater.vis.state
+                state["vision"] = dict(master={k: v.cpu() for k, v in vs.master.items()}, m={k: v.cpu() for k, v in vs.m.items()},
+                                       v={k: v.cpu() for k, v in vs.v.items()})
         if getattr(self.args, "sync_ref_model", False) and self.ref_params is not None:
             state["ref"] = {k: v.cpu() for k, v in self.ref_params.t.items()}     # the reference is no longer --model_id's weights
         torch.save(state, os.path.join(d, "trainer_state.pt"))
@@ -515,6 +541,10 @@ class QwenGRPOTrainer:
             st.step_count = int(state["step_count"])
             for k in st.master:
                 st.master[k].copy_(state["master"][k]); st.m[k].copy_(state["m"][k]); st.v[k].copy_(state["v"][k])
+            if self.updater.vis is not None and "vision" in state:
+                vs = self.updater.vis.state
+                for k in vs.master:
+                    vs.master[k].copy_(state["vision"]["master"][k]); vs.m[k].copy_(state["vision"]["m"][k]); vs.v[k].copy_(state["vision"]["v"][k])
             self.updater.refresh_compute_copies()
         if "ref" in state and self.ref_params is not None:
             for k, v in state["ref"].items():

@@ -121,3 +121,16 @@ def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
     assert [s["step"] for s in steps4] == [1, 2], err4[-3000:]
     for s in steps4:
         assert np.isfinite(s["loss"]) and s["grad_norm"] > 0 and s["completions/mean_length"] > 0
+    # fifth launch: the vision side trainable (train_grpo.py:48-57 of the reference) through the same shell entry -- the tower and the
+    # merger of the saved model moved away from the SFT model's, the LM's too
+    from safetensors.torch import load_file
+    env5 = dict(env, OUTPUT_DIR=str(tmp_path / "out_vis"))
+    steps5, err5 = _launch(env5, *flags, "--max_steps", "2", "--freeze_vision_tower", "False", "--freeze_merger", "False")
+    assert [s["step"] for s in steps5] == [1, 2], err5[-3000:]
+    assert steps5[0]["kl"] == 0.0 and steps5[1]["kl"] > 0.0 and all(np.isfinite(s["loss"]) and s["grad_norm"] > 0 for s in steps5)
+    assert "vision tower" in err5 and "merger" in err5
+    sft, got = load_file(str(model_dir / "model.safetensors")), load_file(str(tmp_path / "out_vis" / "model.safetensors"))
+    for k in ("visual.blocks.0.attn.qkv.weight", "visual.blocks.3.mlp.down_proj.bias", "visual.patch_embed.proj.weight",
+              "visual.merger.mlp.2.weight", "visual.merger.mlp.0.bias", "model.layers.0.self_attn.o_proj.weight"):   # (norm weights near 1
+        # move by less than half a bf16 ulp of the saved file in two steps of 1e-3; their fp32 masters are in trainer_state.pt)
+        assert not np.array_equal(sft[k].float().numpy(), got[k].float().numpy()), k

@@ -296,7 +296,7 @@ def test_sync_ref_model_mixes_the_policy_into_the_reference():
     assert moved >= 4                                                                # the policy had moved (lr 1e-2), so did the reference
 
 
-def _dp_worker(rank, world, port, q, backend="gloo", wire="fp32"):
+def _dp_worker(rank, world, port, q, backend="gloo", wire="fp32", vision=False):
     import os
     local = rank if backend == "nccl" else 0                     # RCCL wants one GPU per rank; the gloo rehearsal shares GPU 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local),
@@ -314,6 +314,7 @@ def _dp_worker(rank, world, port, q, backend="gloo", wire="fp32"):
     args = params.parse_args(["--num_generations", "4", "--max_completion_length", "8", "--beta", "0.04", "--loss_type", "bnpo",
                               "--reward_func_names", "format_reward", "--reward_weights", "1.0", "--learning_rate", "1e-3",
                               "--grad_exchange_dtype", wire])
+    args.train_vision_tower = args.train_merger = vision         # as train_grpo.py's check_trainable_set sets them
 
     def processing_fn(ex):
         frames = torch.randint(0, 256, (2, 3, 56, 56), generator=torch.Generator().manual_seed(ex["vid"]), dtype=torch.uint8).numpy()
@@ -331,12 +332,13 @@ def _dp_worker(rank, world, port, q, backend="gloo", wire="fp32"):
     torch.cuda.synchronize()
     assert tr.updater._works == {}                               # every bucket was exchanged and waited for
     q.put((rank, [ex["vid"] for ex in steps[0]], out["metrics"]["loss"], out["metrics"]["grad_norm"],
-           m.text["l0.o_w"].float().sum().item(), m.text["l1.ln2"].sum().item()))
+           m.text["l0.o_w"].float().sum().item(), m.text["l1.ln2"].sum().item() + m.vision["b1.qkv_w"].float().sum().item()
+           + m.vision["fc2_b"].sum().item()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+@pytest.mark.parametrize("wire", ["fp32", "bf16", "fp32+vision", "bf16+vision"])
 def test_two_rank_dp_step_keeps_replicas_identical(wire):
     """world_size 2 on the one GPU (gloo collectives): ranks take different prompt groups, all-reduce the gradients and must end
     the step with bit-identical weights and identical reduced metrics -- with the fp32 arena on the wire and with the bf16 wire
@@ -346,7 +348,8 @@ def test_two_rank_dp_step_keeps_replicas_identical(wire):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, "gloo", wire)) for r in range(2)]
+    vision = wire.endswith("+vision")                            # the tower and the merger train too: their bucket is exchanged as well
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, "gloo", wire.split("+")[0], vision)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(2))

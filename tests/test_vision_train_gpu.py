@@ -157,3 +157,49 @@ def test_optimizer_step_moves_the_tower_and_the_next_encode_sees_it():
     (emb1, _), = eng.encode_videos(clips, per_prompt=[1])
     (embf, _), = eng.encode_videos(clips, per_prompt=[1], vision=frozen)
     assert not torch.equal(emb1, emb0) and torch.equal(embf.clone(), emb0)   # the policy's tower moved, the frozen copy did not
+
+
+def test_grpo_trainer_with_the_vision_side_trainable(tmp_path):
+    """QwenGRPOTrainer with --freeze_vision_tower False --freeze_merger False (as train_grpo.py's check_trainable_set hands them over):
+    step 1 still has kl == 0 exactly (the frozen copy of the tower + LM == the policy), the update moves the policy's tower and not
+    the reference's, step 2 sees kl > 0, and a checkpoint carries the trained tower (HF-layout weights + optimiser state)."""
+    import os
+    from tests.test_model_gpu import _model
+    from video_r2_amd import params, rewards
+    from video_r2_amd.model import VideoR2Model
+    from video_r2_amd.trainer import QwenGRPOTrainer
+    m, w, ocfg = _model(2, 31)
+    cfg = m.cfg
+    args = params.parse_args(["--num_generations", "4", "--max_completion_length", "10", "--beta", "0.04", "--loss_type", "bnpo",
+                              "--learning_rate", "1e-3", "--reward_func_names", "format_reward", "--reward_weights", "1.0",
+                              "--freeze_vision_tower", "False", "--freeze_merger", "False"])
+    args.train_vision_tower, args.train_merger = True, True
+
+    def processing_fn(ex):
+        frames = torch.randint(0, 256, (2, 3, 56, 56), generator=torch.Generator().manual_seed(ex["vid"]), dtype=torch.uint8).numpy()
+        px, grid = pixels_from_frames(frames, cfg.vision)
+        tv = grid[0] * grid[1] * grid[2] // 4
+        ids = [40 + ex["vid"], cfg.vision_start_token_id] + [cfg.video_token_id] * tv + [cfg.vision_end_token_id, 50, 51]
+        return dict(input_ids=np.asarray(ids), pixel_values_videos=torch.from_numpy(px).cuda(), video_grid_thw=[grid], second_per_grid_ts=[1.0],
+                    decode=lambda toks: ["<think>t</think> <answer>B</answer>" if i % 2 else "nope" for i in range(toks.shape[0])])
+
+    data = [dict(prompt=[{"role": "user", "content": "q"}], vid=i) for i in range(3)]
+    funcs, wts, names = rewards.load_reward_funcs("video_r2_amd.rewards", args)
+    tr = QwenGRPOTrainer(m, funcs, args, data, processing_fn, reward_weights=wts, reward_func_names=names)
+    assert tr.updater.vis is not None and tr.ref_vision is not None
+    steps = list(tr.iter_steps())
+    fc2_0, qkv_0 = m.vision["fc2_w"].clone(), m.vision["b0.qkv_w"].clone()
+    o1 = tr.step(steps[0])
+    assert o1["metrics"]["kl"] == 0.0 and torch.equal(o1["rollouts"][0]["ref_logps"], o1["rollouts"][0]["logps"])
+    assert not torch.equal(m.vision["fc2_w"], fc2_0) and not torch.equal(m.vision["b0.qkv_w"], qkv_0)      # the policy's tower moved
+    assert torch.equal(tr.ref_vision["fc2_w"], fc2_0) and torch.equal(tr.ref_vision["b0.qkv_w"], qkv_0)    # the reference's did not
+    o2 = tr.step(steps[1])
+    assert o2["metrics"]["kl"] > 0.0 and np.isfinite(o2["loss"])
+    d = tr.save_checkpoint(str(tmp_path))
+    m2 = VideoR2Model.from_pretrained(d)
+    assert torch.equal(m2.vision["fc2_w"], m.vision["fc2_w"]) and torch.equal(m2.vision["b0.qkv_w"], m.vision["b0.qkv_w"])
+    tr2 = QwenGRPOTrainer(m2, funcs, args, data, processing_fn, reward_weights=wts, reward_func_names=names).load_checkpoint(d)
+    for k in tr.updater.vis.state.master:
+        assert torch.equal(tr.updater.vis.state.master[k], tr2.updater.vis.state.master[k]), k
+        assert torch.equal(tr.updater.vis.state.m[k], tr2.updater.vis.state.m[k]), k
+    assert os.path.exists(os.path.join(d, "trainer_state.pt"))

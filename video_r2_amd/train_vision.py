@@ -44,10 +44,12 @@ class VisionState:
         if train_tower:
             mats += ["patch_w"] + [f"b{i}.{n}" for i in range(v.depth) for n in ("qkv_w", "proj_w", "gu_w", "down_w")]
             vecs += [f"b{i}.{n}" for i in range(v.depth) for n in ("norm1", "norm2", "qkv_b", "proj_b", "gu_b", "down_b")]
-        for name in mats:
+        through = ["fc1_w", "fc2_w"] if train_tower and not train_merger else []   # frozen merger above a trainable tower: the
+        for name in mats + through:                                                # gradient still passes through its W^T
             n, kp = vision.shape[name]
             w = unpack_tiles(vision[name], n, kp)                    # [N][Kp] bf16 (K padding columns are zero)
-            self._add(name, w.float(), "mat", True)
+            if name not in through:
+                self._add(name, w.float(), "mat", True)
             wt = torch.zeros((kp, pad64(n)), dtype=torch.bfloat16, device=device)
             wt[:, :n] = w.t()
             vision.t[name + "_t"] = pack_tiles(wt)
@@ -204,8 +206,8 @@ class VisionTrainer:
         # ---- ViT blocks, last to first
         kw_win, kw_full = self._keywork(pl)
         dact = b("tv.dact", (P, Ip), torch.bfloat16, zero=True)
-        dgu = b("tv.dgu", (P, 2 * I16), torch.bfloat16)
-        dxn = b("tv.dxn", (P, Hv), torch.float32)
+        dgu = b("tv.dgu", (P, pad64(2 * I16)), torch.bfloat16, zero=True)      # K operand of the gu dgrad: padded to its tile
+        dxn = b("tv.dxn", (P, Hp), torch.float32)                               # the transposed copies have pad64(Hv) output columns
         datt = b("tv.datt", (P, Hp), torch.bfloat16, zero=True)
         W128 = nh * 128
         q128, k128, v128 = (b("tv.%s128" % n, (P, W128), torch.bfloat16, zero=True) for n in "qkv")
@@ -234,7 +236,7 @@ class VisionTrainer:
             self._colsum(dgu, f"b{i}.gu_b", P, 2 * I16)
             self._gemm(dgu, f"b{i}.gu_w_t", None, dxn, P, EPI_F32)
             self._wgrad(dgu, sv["xn2"][i], f"b{i}.gu_w", 2 * I16, Hp, P)
-            lib.call("vr2_rmsnorm_bwd", sv["x_mid"][i], Hv, W[f"b{i}.norm2"], dxn, Hv, dx, Hv, rinv, st.grad[f"b{i}.norm2"], P, Hv, 1e-6, 1,
+            lib.call("vr2_rmsnorm_bwd", sv["x_mid"][i], Hv, W[f"b{i}.norm2"], dxn, dxn.stride(0), dx, Hv, rinv, st.grad[f"b{i}.norm2"], P, Hv, 1e-6, 1,
                      dxb, dxb.stride(0), eng.s)
             # attention
             self._colsum(dxb, f"b{i}.proj_b", P, Hv)
@@ -256,7 +258,7 @@ class VisionTrainer:
             self._colsum(dqkv, f"b{i}.qkv_b", P, 3 * Hv)
             self._gemm(dqkv, f"b{i}.qkv_w_t", None, dxn, P, EPI_F32)
             self._wgrad(dqkv, sv["xn1"][i], f"b{i}.qkv_w", 3 * Hv, Hp, P)
-            lib.call("vr2_rmsnorm_bwd", sv["x_in"][i], Hv, W[f"b{i}.norm1"], dxn, Hv, dx, Hv, rinv, st.grad[f"b{i}.norm1"], P, Hv, 1e-6, 1,
+            lib.call("vr2_rmsnorm_bwd", sv["x_in"][i], Hv, W[f"b{i}.norm1"], dxn, dxn.stride(0), dx, Hv, rinv, st.grad[f"b{i}.norm1"], P, Hv, 1e-6, 1,
                      dxb, dxb.stride(0), eng.s)
         # ---- patch embedding: dW += dx^T a0 (the pixels carry no gradient)
         a0 = sv["a0"]

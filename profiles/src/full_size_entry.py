@@ -2,7 +2,8 @@
 array clips at the reference geometry (360 x 640 source frames -> 280 x 504 under --video_max_pixels 360*420, <= 32 frames) with one
 still-image row, then `bash train/scripts/train_grpo.sh` on ONE GPU for a few optimiser steps.  Not a test (it writes ~17 GB and
 runs for minutes): it answers "does the recipe fit and run at 7B through the entry point a user launches".
-Usage: python profiles/src/full_size_entry.py <workdir> [steps] [groups_per_step] [max_completion_length] [frames per clip @ 30 fps]"""
+Usage: python profiles/src/full_size_entry.py <workdir> [steps] [groups_per_step] [max_completion_length] [frames per clip @ 30 fps]
+(VR2_ENTRY_FLAGS="--freeze_vision_tower False ..." appends flags to the launch line)"""
 import json
 import os
 import subprocess
@@ -61,7 +62,7 @@ for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
     env.pop(k, None)
 flags = ["--per_device_train_batch_size", str(8 * groups), "--max_completion_length", str(C), "--max_steps", str(steps),
          "--reward_func_names", "accuracy_reward,format_reward", "--reward_weights", "1.0,1.0", "--logging_steps", "1",
-         "--save_steps", "100000", "--image_max_pixels", str(360 * 420)]
+         "--save_steps", "100000", "--image_max_pixels", str(360 * 420)] + os.environ.get("VR2_ENTRY_FLAGS", "").split()
 t0 = time.time()
 r = subprocess.run(["bash", os.path.join(ROOT, "train", "scripts", "train_grpo.sh"), *flags], env=env, capture_output=True, text=True)
 print(r.stdout[-4000:])

@@ -134,3 +134,13 @@ def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
               "visual.merger.mlp.2.weight", "visual.merger.mlp.0.bias", "model.layers.0.self_attn.o_proj.weight"):   # (norm weights near 1
         # move by less than half a bf16 ulp of the saved file in two steps of 1e-3; their fp32 masters are in trainer_state.pt)
         assert not np.array_equal(sft[k].float().numpy(), got[k].float().numpy()), k
+    # sixth launch: --freeze_llm True under a trainable merger (configure_llm + configure_vision_tower): the merger moves, the LM and the
+    # frozen tower are written back exactly as they came
+    env6 = dict(env, OUTPUT_DIR=str(tmp_path / "out_merger"))
+    steps6, err6 = _launch(env6, *flags, "--max_steps", "2", "--freeze_llm", "True", "--freeze_merger", "False")
+    assert [s["step"] for s in steps6] == [1, 2], err6[-3000:]
+    assert all(np.isfinite(s["loss"]) and s["grad_norm"] > 0 for s in steps6)
+    got6 = load_file(str(tmp_path / "out_merger" / "model.safetensors"))
+    assert not np.array_equal(sft["visual.merger.mlp.2.weight"].float().numpy(), got6["visual.merger.mlp.2.weight"].float().numpy())
+    for k in ("visual.blocks.0.attn.qkv.weight", "model.layers.0.self_attn.o_proj.weight", "lm_head.weight", "model.embed_tokens.weight"):
+        assert np.array_equal(sft[k].float().numpy(), got6[k].float().numpy()), k

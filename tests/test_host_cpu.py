@@ -35,8 +35,8 @@ def test_trainable_set_follows_the_freeze_flags():
                         ("--freeze_vision_tower True --freeze_merger False", (False, True)), ("", (True, True))):
         a = params.parse_args(base + flags.split())
         assert entry.check_trainable_set(a) == want and (a.train_vision_tower, a.train_merger) == want
-    with pytest.raises(NotImplementedError, match="freeze_llm"):
-        entry.check_trainable_set(params.parse_args(base + "--freeze_llm True --freeze_merger False --freeze_vision_tower True".split()))
+    # --freeze_llm True under a trainable merger: accepted (the LM's backward then computes input gradients only)
+    assert entry.check_trainable_set(params.parse_args(base + "--freeze_llm True --freeze_merger False --freeze_vision_tower True".split())) == (False, True)
     entry.check_trainable_set(params.parse_args(base + "--freeze_llm True --freeze_merger True --freeze_vision_tower True".split()))
 
 

@@ -203,3 +203,45 @@ def test_grpo_trainer_with_the_vision_side_trainable(tmp_path):
         assert torch.equal(tr.updater.vis.state.master[k], tr2.updater.vis.state.master[k]), k
         assert torch.equal(tr.updater.vis.state.m[k], tr2.updater.vis.state.m[k]), k
     assert os.path.exists(os.path.join(d, "trainer_state.pt"))
+
+
+def test_frozen_lm_under_a_trainable_vision_side():
+    """--freeze_llm True with --freeze_vision_tower False / --freeze_merger False (configure_llm + configure_vision_tower of the
+    reference): the LM's backward computes input gradients only.  The vision gradients are those of the run that also trains the LM
+    (same launches on the way down), the LM holds no masters / gradients / moments, its weights do not move, and
+    the clip norm is the vision tensors' alone."""
+    from video_r2_amd.host import grpo as hg
+    from video_r2_amd.train import Trainer
+    from video_r2_amd.train_vision import VisionTrainer
+    ocfg, eng, w, cfg, frames, px, grid, prompt, comp = _setup(2, 83)
+    clips = [dict(frames_u8=frames, resize_to=None)]
+    (emb0, plan), = eng.encode_videos(clips, per_prompt=[1])
+    emb0 = emb0.clone()
+    rows, _ = eng.encode_videos(clips, per_prompt=[1], rows_only=True)
+    mask, _, _ = ints.completion_mask(comp.numpy(), cfg.eos_token_id)
+    adv = torch.tensor([1.0, -1.0, 0.3], device=eng.device)
+    grads = {}
+    for mode in ("full", "frozen_lm"):
+        vt = VisionTrainer(eng, eng.vision, True, True)
+        tr = Trainer(eng, eng.text, vision_trainer=vt, train_lm=(mode == "full"))
+        lp = tr.forward(prompt, emb0, plan, [1.0], comp, 0.9, vision_rows=rows)
+        out = hg.grpo_loss(lp, torch.from_numpy(mask).to(eng.device), adv, ref_logps=lp.clone() - 0.01, beta=0.04, loss_type="bnpo",
+                           stream=torch.cuda.current_stream().cuda_stream)
+        tr.backward(out["dlogp"])
+        eng.sync()
+        grads[mode] = {k: v.clone() for k, v in vt.state.grad.items()}
+        if mode == "frozen_lm":
+            assert tr.state.master == {} and tr.state.arena.numel() == 0
+            before = {k: eng.text[k].clone() for k in ("l0.qkv_w", "l1.down_w", "lm_head", "embed", "norm")}
+            fc2 = eng.vision["fc2_w"].clone()
+            gn = tr.optimizer_step(lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+            eng.sync()
+            total = torch.sqrt(sum((x.double() ** 2).sum() for x in grads[mode].values())).item()
+            assert abs(gn.item() - total) < 1e-3 * total
+            assert all(torch.equal(eng.text[k], v) for k, v in before.items()) and not torch.equal(eng.vision["fc2_w"], fc2)
+        del tr, vt
+    assert set(grads["full"]) == set(grads["frozen_lm"])
+    for k in grads["full"]:     # same launches on the way down; the fp32 atomic adds of dK / dV, the column sums and the norm weights
+        a, b_ = grads["full"][k], grads["frozen_lm"][k]     # arrive in a different order from run to run: 1e-5 of the tensor's norm
+        assert (a - b_).norm().item() <= 1e-5 * a.norm().item(), k
+    assert max(float(v.abs().max()) for v in grads["full"].values()) > 0

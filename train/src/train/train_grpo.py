@@ -136,12 +136,9 @@ def check_trainable_set(args):
     """Which parameter sets train (train_grpo.py:48-64 of the reference: `configure_vision_tower` sets requires_grad on model.visual
     from --freeze_vision_tower and then on model.visual.merger from --freeze_merger; `configure_llm` on the LM from --freeze_llm).
     The flags' parsed defaults are the reference's: False = trainable.  -> (train_tower, train_merger), also set on `args` as
-    `train_vision_tower` / `train_merger` for QwenGRPOTrainer.  The one combination this engine cannot run -- the vision side
-    trainable with the LM frozen (its gradient arrives through the LM's backward pass) -- is refused, not downgraded."""
+    `train_vision_tower` / `train_merger` for QwenGRPOTrainer.  Every combination runs: with --freeze_llm True under a trainable vision
+    side the LM's backward pass computes input gradients only (the vision gradient arrives through it)."""
     tower, merger = not args.freeze_vision_tower, not args.freeze_merger
-    if (tower or merger) and args.freeze_llm:
-        raise NotImplementedError("--freeze_llm True with --freeze_vision_tower False / --freeze_merger False: the vision side trains through "
-                                  "the LM's backward pass here; unfreeze the LM or freeze the vision side")
     args.train_vision_tower, args.train_merger = tower, merger
     return tower, merger
 

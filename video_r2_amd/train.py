@@ -36,9 +36,12 @@ class TrainState:
     gradient is enqueued and running on RCCL's stream under the rest of the backward (the single
     gradient exchange that replaces ZeRO-3's gathers / reduce-scatters)."""
 
-    def __init__(self, text: Params, device):
+    def __init__(self, text: Params, device, trainable=True):
+        """trainable=False (--freeze_llm True under a trainable vision side): the LM keeps no masters, gradients or moments -- only the
+        transposed copies its input gradients need on their way down to the vision tower."""
         self.text = text
         self.device = device
+        self.trainable = trainable
         self.master, self.grad, self.m, self.v = {}, {}, {}, {}
         self.kind = {}            # 'mat' | 'rows' | 'vec'
         self.decay = {}
@@ -50,12 +53,20 @@ class TrainState:
         for name in mats:
             n, kp = text.shape[name]
             w = unpack_tiles(text[name], n, kp)                      # [N][Kp] bf16 (K padding columns are zero)
-            self._add(name, w.float(), "mat", True)
+            if trainable:
+                self._add(name, w.float(), "mat", True)
             wt = torch.zeros((kp, pad64(n)), dtype=torch.bfloat16, device=device)
             wt[:, :n] = w.t()
             text.t[name + "_t"] = pack_tiles(wt)
             text.shape[name + "_t"] = (kp, pad64(n))
         self.tied = t.tie_word_embeddings
+        self.step_count = 0
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self.coef = torch.ones(1, dtype=torch.float32, device=device)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
+        self.arena, self.buckets = torch.zeros(0, dtype=torch.float32, device=device), []
+        if not trainable:
+            return
         self._add("embed", text["embed"].float(), "rows", True)
         vecs = [f"l{i}.{n}" for i in range(L) for n in ("ln1", "ln2", "qkv_b")] + ["norm"]
         for name in vecs:
@@ -76,10 +87,6 @@ class TrainState:
                 self.grad[n] = self.arena[at:at + k].view(self.master[n].shape)
                 at += k
             self.buckets.append((key, first, at))
-        self.step_count = 0
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=device)
-        self.coef = torch.ones(1, dtype=torch.float32, device=device)
-        self.gnorm = torch.zeros(1, dtype=torch.float32, device=device)
 
     def _add(self, name, master, kind, decay):
         self.master[name] = master.contiguous()
@@ -99,7 +106,7 @@ class Trainer:
     """Training forward / backward / optimiser step on an Engine (shares its stream and workspaces)."""
     KEEP_LOGITS_BYTES = 8 << 30      # forward() keeps a prompt group's fp32 logits for backward() up to this size
 
-    def __init__(self, engine: Engine, text: Params, grad_exchange="fp32", vision_trainer=None):
+    def __init__(self, engine: Engine, text: Params, grad_exchange="fp32", vision_trainer=None, train_lm=True):
         """grad_exchange: wire format of the data-parallel gradient all-reduce.  "fp32" (default) exchanges the fp32 arena as it
         is (30.5 GB per step at 7B: the exact mean of the ranks' fp32 gradients).  "bf16" rounds every bucket to bfloat16 on the
         way out, sums in bfloat16 on the wire and widens the result back into the arena: 15.2 GB per step -- the figure of the
@@ -107,12 +114,17 @@ class Trainer:
         reduced values either way, so replicas stay bit-identical.
         vision_trainer: a train_vision.VisionTrainer when the vision tower and / or the merger train (--freeze_vision_tower False /
         --freeze_merger False): forward() then runs the tower with saved activations from the patch rows it is handed, backward() hands
-        the input gradient at the video-token rows down to it, and optimizer_step() clips and updates both parameter sets together."""
+        the input gradient at the video-token rows down to it, and optimizer_step() clips and updates both parameter sets together.
+        train_lm=False (--freeze_llm True; needs a vision_trainer): the LM's backward computes input gradients only -- no weight
+        gradients, no masters or moments for the LM -- and the optimiser step covers the vision tensors alone."""
+        if not train_lm and vision_trainer is None:
+            raise ValueError("Trainer(train_lm=False) without a vision_trainer: nothing to train")
         if grad_exchange not in ("fp32", "bf16"):
             raise ValueError(f"grad_exchange must be fp32 or bf16, got {grad_exchange!r}")
         self.eng = engine
         self.text = text
-        self.state = TrainState(text, engine.device)
+        self.train_lm = bool(train_lm)
+        self.state = TrainState(text, engine.device, trainable=self.train_lm)
         self.grad_exchange = grad_exchange
         self.vis = vision_trainer
         self._wire = {}           # bf16 mirrors of the gradient arenas (allocated at the first bf16 exchange)
@@ -133,6 +145,8 @@ class Trainer:
         self.eng._gemm(A, self.text, wname, bias, C, M, epi)
 
     def _wgrad(self, dY, X, name, M_out, N_in, T):
+        if not self.train_lm:
+            return
         g = self.state.grad[name]
         lib.call("vr2_gemm_tn_bf16", dY, dY.stride(0), X, X.stride(0), g, g.stride(0), M_out, N_in, T, 1, self.eng.s)
 
@@ -250,6 +264,8 @@ class Trainer:
         stage's bucket is all-reduced as soon as its weight gradients are enqueued, overlapping the rest of this backward."""
         eng, W, cfg, st = self.eng, self.text, self.eng.cfg, self.state
         exchange = exchange and vdist.world_size() > 1 and not st.tied     # tied lm_head / embedding: summed first, at the step
+        lm_exchange = exchange and self.train_lm
+        gr = (lambda n: st.grad[n]) if self.train_lm else (lambda n: None)   # frozen LM: the norm kernels skip their weight gradient
         s = self._saved
         assert s is not None, "backward() needs a preceding forward()"
         t = cfg.text
@@ -280,8 +296,8 @@ class Trainer:
             self._wgrad(dz, s["hn"][r0:r0 + n], "lm_head", V, H, n)
         dhs = b("t.dhs", (R, H), torch.float32)
         rinv = b("t.rinv", (max(T, R),), torch.float32)
-        lib.call("vr2_rmsnorm_bwd", s["hs"], H, W["norm"], dhn, H, dhs, H, rinv, st.grad["norm"], R, H, t.rms_norm_eps, 0, None, 0, eng.s)
-        if exchange:
+        lib.call("vr2_rmsnorm_bwd", s["hs"], H, W["norm"], dhn, H, dhs, H, rinv, gr("norm"), R, H, t.rms_norm_eps, 0, None, 0, eng.s)
+        if lm_exchange:
             self._exchange("head")
         dx = b("t.dx", (T, H), torch.float32)
         dx.zero_()
@@ -312,7 +328,7 @@ class Trainer:
             lib.call("vr2_swiglu_bwd", gu, gu.stride(0), dact, dact.stride(0), dgu, dgu.stride(0), T, I16, eng.s)
             self._gemm(dgu, f"l{l}.gu_w_t", None, dxn, T, EPI_F32)
             self._wgrad(dgu, sv["xn2"][l], f"l{l}.gu_w", 2 * I16, H, T)
-            lib.call("vr2_rmsnorm_bwd", sv["x_mid"][l], H, W[f"l{l}.ln2"], dxn, H, dx, H, rinv, st.grad[f"l{l}.ln2"], T, H,
+            lib.call("vr2_rmsnorm_bwd", sv["x_mid"][l], H, W[f"l{l}.ln2"], dxn, H, dx, H, rinv, gr(f"l{l}.ln2"), T, H,
                      t.rms_norm_eps, 1, dxb, dxb.stride(0), eng.s)
             # ---- attention
             self._gemm(dxb, f"l{l}.o_w_t", None, datt, T, EPI_BF16)
@@ -325,18 +341,20 @@ class Trainer:
             lib.call("vr2_attn_bwd_dkv", s["kwork"], s["kwork"].shape[0], q, q.stride(0), k, v, k.stride(0), datt, rowc, T, dk, dvv,
                      nq, t.group, hd, scale, eng.s)
             lib.call("vr2_rope_bwd", dq, dq.stride(0), dk, dvv, dk.stride(0), s["cos"], s["sin"], T, nq, nkv, hd, dqkv, dqkv.stride(0), eng.s)
-            lib.call("vr2_colsum_bf16", dqkv, dqkv.stride(0), st.grad[f"l{l}.qkv_b"], T, nqkv, eng.s)
+            if self.train_lm:
+                lib.call("vr2_colsum_bf16", dqkv, dqkv.stride(0), st.grad[f"l{l}.qkv_b"], T, nqkv, eng.s)
             self._gemm(dqkv, f"l{l}.qkv_w_t", None, dxn, T, EPI_F32)
             self._wgrad(dqkv, sv["xn1"][l], f"l{l}.qkv_w", nqkv, H, T)
-            lib.call("vr2_rmsnorm_bwd", sv["x_in"][l], H, W[f"l{l}.ln1"], dxn, H, dx, H, rinv, st.grad[f"l{l}.ln1"], T, H,
+            lib.call("vr2_rmsnorm_bwd", sv["x_in"][l], H, W[f"l{l}.ln1"], dxn, H, dx, H, rinv, gr(f"l{l}.ln1"), T, H,
                      t.rms_norm_eps, 1, dxb, dxb.stride(0), eng.s)
-            if exchange:
+            if lm_exchange:
                 self._exchange(l)
         # ---- embedding rows (video placeholder rows carry frozen vision features: no gradient)
-        skip = _i32([cfg.video_token_id if s["has_video"] else -1], eng.device)
-        ge = st.grad["embed"]
-        lib.call("vr2_embed_bwd", s["ids"], skip, dx, dx.stride(0), ge, ge.stride(0), T, H, eng.s)
-        if exchange:
+        if self.train_lm:
+            skip = _i32([cfg.video_token_id if s["has_video"] else -1], eng.device)
+            ge = st.grad["embed"]
+            lib.call("vr2_embed_bwd", s["ids"], skip, dx, dx.stride(0), ge, ge.stride(0), T, H, eng.s)
+        if lm_exchange:
             self._exchange("embed")
         if s.get("vis_dst") is not None:
             # the video-token rows of the LM input carry the vision side's output: their input gradient, in the window order the
@@ -371,7 +389,7 @@ class Trainer:
         """All-reduce (mean) the gradients over ranks, clip by global norm, AdamW on the fp32 masters, re-emit bf16 copies,
         zero the gradients.  grad_scale = 1 / (gradient accumulation count).  Returns the pre-clip global norm (0-d tensor)."""
         eng, st, W = self.eng, self.state, self.text
-        if st.tied:
+        if st.tied and self.train_lm:
             st.grad["embed"].add_(st.grad["lm_head"])        # one shared parameter (Qwen2.5-VL-3B)
         world = vdist.world_size()
         if world > 1:

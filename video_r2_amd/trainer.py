@@ -159,24 +159,24 @@ class QwenGRPOTrainer:
         self.prof = PhaseTimer("QwenGRPOTrainer", stream=model.engine.stream, enabled=getattr(args, "profile_phases", True))
         self._reward_pool = None                     # background thread for the reward functions (see _rollout_all)
         self._row_pool = None                        # --reward_workers threads that split a reward function's rows
-        self.update = not getattr(args, "freeze_llm", False)
+        train_lm = not getattr(args, "freeze_llm", False)
         # the vision side trains when asked (train_grpo.py:48-57: requires_grad of model.visual from freeze_vision_tower, then of
         # model.visual.merger from freeze_merger).  Parsed defaults are the reference's (both False = trainable); a trainer built
         # from arguments that do not mention them at all (tests, embedding callers) keeps the frozen default of the shipped recipe
         self.train_tower = getattr(args, "train_vision_tower", False)
         self.train_merger = getattr(args, "train_merger", False)
+        self.update = train_lm or self.train_tower or self.train_merger       # anything to train at all
         self.ref_vision = None
         vis_tr = None
         if self.train_tower or self.train_merger:
-            if not self.update:
-                raise NotImplementedError("--freeze_llm True with a trainable vision tower / merger: the vision side trains through the "
-                                          "LM's backward pass, which --freeze_llm switches off in this engine")
             from .train_vision import VisionTrainer
             if self.ref_params is not None:      # the frozen reference model keeps the ORIGINAL tower (its own copy, as the reference's)
                 self.ref_vision = vw.clone_params(model.vision)
             vis_tr = VisionTrainer(model.engine, model.vision, self.train_tower, self.train_merger)
-        self.updater = (UpdateEngine(model.engine, model.text, grad_exchange=getattr(args, "grad_exchange_dtype", "fp32"), vision_trainer=vis_tr)
-                        if self.update else None)
+        # --freeze_llm True under a trainable vision side (configure_llm, train_grpo.py:59-64): the LM's backward still runs -- the
+        # vision gradient arrives through it -- but computes input gradients only
+        self.updater = (UpdateEngine(model.engine, model.text, grad_exchange=getattr(args, "grad_exchange_dtype", "fp32"), vision_trainer=vis_tr,
+                                     train_lm=train_lm) if self.update else None)
         self.steps_per_epoch = len(train_dataset) // self.groups_per_step
         n_steps = int(self.steps_per_epoch * float(args.num_train_epochs)) * max(1, args.num_iterations)
         self.total_steps = args.max_steps if args.max_steps > 0 else max(1, n_steps)

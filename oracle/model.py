@@ -290,12 +290,19 @@ def mrope_cos_sin(cfg: Cfg, position_ids):
 
 
 def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv_cache=None, emulate_bf16=False, act_quant=None,
-               rounding=None, layer_inputs=None):
+               rounding=None, layer_inputs=None, lora=None):
     """HF:790-872 + decoder layers :641-757.  inputs_embeds [B,S,H]; position_ids [3,B,S];
     attention_mask [B, S_total] over cached+new keys (1 = attend).  kv_cache: list of (k,v) [B,Hkv,T,hd]
     (updated in place when given).  Returns final-normed hidden [B,S,H].  rounding: see _rounders.
-    layer_inputs: a list that receives the residual stream entering every layer (tests that check one layer at a time)."""
+    layer_inputs: a list that receives the residual stream entering every layer (tests that check one layer at a time).
+    lora: {HF weight name: callable(input) -> the adapter branch's output} (oracle/sft.py: peft's lora.Linear.forward adds
+    lora_B(lora_A(dropout(x))) * scaling to the base layer's result)."""
     rd, ro = _rounders(emulate_bf16, rounding)
+
+    def lin(h_, name):
+        y = h_ @ w[name].t()
+        return y + lora[name](h_) if (lora is not None and name in lora) else y
+
     aq = act_quant if act_quant is not None else _ident       # applied to the input of every projection (config 5, fp8 activations)
     t = cfg.text
     B, S, H = inputs_embeds.shape
@@ -317,9 +324,9 @@ def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv
         if layer_inputs is not None:
             layer_inputs.append(x.clone())
         h = aq(ro(rms_norm(x, w[p + "input_layernorm.weight"], t.rms_norm_eps, rd)))
-        q = rd(h @ w[p + "self_attn.q_proj.weight"].t() + w[p + "self_attn.q_proj.bias"]).view(B, S, nh, hd).transpose(1, 2)
-        k = rd(h @ w[p + "self_attn.k_proj.weight"].t() + w[p + "self_attn.k_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
-        v = rd(h @ w[p + "self_attn.v_proj.weight"].t() + w[p + "self_attn.v_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
+        q = rd(lin(h, p + "self_attn.q_proj.weight") + w[p + "self_attn.q_proj.bias"]).view(B, S, nh, hd).transpose(1, 2)
+        k = rd(lin(h, p + "self_attn.k_proj.weight") + w[p + "self_attn.k_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
+        v = rd(lin(h, p + "self_attn.v_proj.weight") + w[p + "self_attn.v_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
         q = ro(rd(rd(q * cos) + rd(rotate_half(q) * sin)))
         k = ro(rd(rd(k * cos) + rd(rotate_half(k) * sin)))
         v = ro(v)
@@ -331,10 +338,10 @@ def lm_forward(w, cfg: Cfg, inputs_embeds, position_ids, attention_mask=None, kv
         kr = k.repeat_interleave(nh // nkv, dim=1)
         vr = v.repeat_interleave(nh // nkv, dim=1)
         o = _attend(q, kr, vr, hd ** -0.5, bias, rd, ro).transpose(1, 2).reshape(B, S, nh * hd)
-        x = rd(x + rd(aq(ro(o)) @ w[p + "self_attn.o_proj.weight"].t()))
+        x = rd(x + rd(lin(aq(ro(o)), p + "self_attn.o_proj.weight")))
         h = aq(ro(rms_norm(x, w[p + "post_attention_layernorm.weight"], t.rms_norm_eps, rd)))
-        g = rd(rd(F.silu(rd(h @ w[p + "mlp.gate_proj.weight"].t()))) * rd(h @ w[p + "mlp.up_proj.weight"].t()))
-        x = rd(x + rd(aq(ro(g)) @ w[p + "mlp.down_proj.weight"].t()))
+        g = rd(rd(F.silu(rd(lin(h, p + "mlp.gate_proj.weight")))) * rd(lin(h, p + "mlp.up_proj.weight")))
+        x = rd(x + rd(lin(aq(ro(g)), p + "mlp.down_proj.weight")))
     return ro(rms_norm(x, w["model.norm.weight"], t.rms_norm_eps, rd))
 
 
@@ -363,7 +370,8 @@ def build_inputs_embeds(w, cfg: Cfg, input_ids, video_embeds, image_embeds=None)
 
 
 def forward_logits(w, cfg: Cfg, input_ids, attention_mask, pixel_values_videos, video_grid_thw, second_per_grid_ts,
-                   video_embeds=None, emulate_bf16=False, pixel_values=None, image_grid_thw=None, image_embeds=None, rounding=None):
+                   video_embeds=None, emulate_bf16=False, pixel_values=None, image_grid_thw=None, image_embeds=None, rounding=None,
+                   lora=None):
     """Full forward -> logits [B,S,V] fp32 (HF:1308-1402 without the loss).  Still images (pixel_values, image_grid_thw: the
     `images=` half of the reference's processor call, grpo_trainer.py:759-767) go through the same vision tower in a pass of
     their own, as HF's get_image_features does."""
@@ -378,7 +386,7 @@ def forward_logits(w, cfg: Cfg, input_ids, attention_mask, pixel_values_videos, 
                            image_token_id=cfg.image_token_id, image_grid_thw=image_grid_thw,
                            merge_size=cfg.vision.spatial_merge_size, tokens_per_second=cfg.vision.tokens_per_second)
     h = lm_forward(w, cfg, emb, torch.from_numpy(pos), None if attention_mask is None else torch.as_tensor(attention_mask),
-                   emulate_bf16=emulate_bf16, rounding=rounding)
+                   emulate_bf16=emulate_bf16, rounding=rounding, lora=lora)
     logits = h @ lm_head_weight(w, cfg).t()
     return _rounders(emulate_bf16, rounding)[0](logits)
 
@@ -397,7 +405,7 @@ def per_token_logps(w, cfg, input_ids, attention_mask, logits_to_keep, temperatu
     logits = forward_logits(w, cfg, ids, attention_mask, mm.get("pixel_values_videos"), mm.get("video_grid_thw"),
                             mm.get("second_per_grid_ts"), video_embeds=mm.get("video_embeds"), rounding=rounding,
                             pixel_values=mm.get("pixel_values"), image_grid_thw=mm.get("image_grid_thw"),
-                            image_embeds=mm.get("image_embeds"))
+                            image_embeds=mm.get("image_embeds"), lora=mm.get("lora"))
     logits = logits[:, :-1, :]
     tgt = ids[:, 1:]
     logits = logits[:, -logits_to_keep:]

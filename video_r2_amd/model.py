@@ -157,11 +157,14 @@ class VideoR2Model:
     def state_dict(self):
         return W.export_state_dict(self.cfg, self.vision, self.text)
 
-    def save_pretrained(self, path):
-        from safetensors.torch import save_file
+    def save_config(self, path):
         os.makedirs(path, exist_ok=True)
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(self.cfg.to_dict(), f, indent=2)
+
+    def save_pretrained(self, path):
+        from safetensors.torch import save_file
+        self.save_config(path)
         save_file({k: v.contiguous().cpu() for k, v in self.state_dict().items()}, os.path.join(path, "model.safetensors"),
                   metadata={"format": "pt"})
 

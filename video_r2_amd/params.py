@@ -40,6 +40,18 @@ class GRPOArguments:
     freeze_merger: bool = False
     bf16: bool = True
     fp16: bool = False
+    # LoRA (train_grpo.py:76-93,137-149 of the reference; params.py:147-158)
+    lora_enable: bool = False
+    vision_lora: bool = False
+    use_dora: bool = False
+    lora_rank: int = 64
+    lora_alpha: int = 16
+    lora_dropout: float = 0.05
+    lora_weight_path: str = ""
+    lora_bias: str = "none"
+    lora_namespan_exclude: Optional[str] = None
+    num_lora_modules: int = -1
+    bits: int = 16
     # GRPO
     num_train_epochs: float = 1.0
     max_steps: int = -1
@@ -111,12 +123,85 @@ class GRPOArguments:
 
 
 IGNORED_FLAGS = ("deepspeed", "disable_flash_attn2", "gradient_checkpointing", "tf32", "lazy_preprocess", "cache_dir", "optim",
-                 "lora_enable", "use_liger", "local_rank")
+                 "use_liger", "local_rank", "double_quant", "quant_type", "max_seq_length")
 
 
-def parse_args(argv=None) -> GRPOArguments:
+@dataclass
+class SFTArguments:
+    """train/src/params.py:14-59 (TrainingArguments over HF's) + DataArguments + ModelArguments, as train_sft.sh:27-66 sets them"""
+    model_id: str = "Qwen/Qwen2-VL-7B-Instruct"
+    data_path: Optional[str] = None
+    image_folder: Optional[str] = None
+    video_subtitles_folder: Optional[str] = None
+    output_dir: str = "output"
+    image_min_pixels: int = 3136
+    image_max_pixels: int = 12845056
+    video_min_pixels: int = 100352
+    video_max_pixels: int = 602112
+    image_resized_width: Optional[int] = None
+    image_resized_height: Optional[int] = None
+    video_resized_width: Optional[int] = None
+    video_resized_height: Optional[int] = None
+    fps: float = 1.0
+    freeze_vision_tower: bool = False
+    freeze_llm: bool = False
+    freeze_merger: bool = False
+    bf16: bool = True
+    fp16: bool = False
+    # LoRA (train_sft.sh:30-37)
+    lora_enable: bool = False
+    vision_lora: bool = False
+    use_dora: bool = False
+    lora_rank: int = 64
+    lora_alpha: int = 16
+    lora_dropout: float = 0.05
+    lora_weight_path: str = ""
+    lora_bias: str = "none"
+    lora_namespan_exclude: Optional[str] = None
+    num_lora_modules: int = -1
+    bits: int = 16
+    # schedule / optimiser (HF TrainingArguments names and defaults; train_sft.sh:50-66)
+    num_train_epochs: float = 1.0
+    max_steps: int = -1
+    per_device_train_batch_size: int = 1
+    gradient_accumulation_steps: int = 1
+    learning_rate: float = 5e-5
+    vision_lr: Optional[float] = None
+    merger_lr: Optional[float] = None
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 1.0
+    lr_scheduler_type: str = "cosine"
+    warmup_ratio: float = 0.0
+    warmup_steps: int = 0
+    seed: int = 42
+    logging_steps: int = 10
+    save_strategy: str = "steps"
+    save_steps: int = 500
+    save_total_limit: int = 2
+    report_to: str = "none"
+    dataloader_num_workers: int = 0
+    remove_unused_columns: bool = False
+    resume_from_checkpoint: str = ""
+    grad_exchange_dtype: str = "fp32"
+    ignored: dict = field(default_factory=dict)
+
+
+def parse_sft_args(argv=None) -> SFTArguments:
+    a = _parse(SFTArguments, argv, IGNORED_FLAGS)
+    _check_lora(a)
+    if a.grad_exchange_dtype not in ("fp32", "bf16"):
+        raise ValueError(f"--grad_exchange_dtype must be fp32 or bf16, got {a.grad_exchange_dtype}")
+    if a.lr_scheduler_type not in ("cosine", "constant"):
+        raise NotImplementedError(f"--lr_scheduler_type {a.lr_scheduler_type}: cosine (the shipped recipe) and constant are built")
+    return a
+
+
+def _parse(cls, argv, ignored_flags):
     p = argparse.ArgumentParser(allow_abbrev=False)
-    for f in fields(GRPOArguments):
+    for f in fields(cls):
         if f.name == "ignored":
             continue
         typ = f.type if isinstance(f.type, type) else None
@@ -133,11 +218,11 @@ def parse_args(argv=None) -> GRPOArguments:
             p.add_argument(f"--{f.name}", type=lambda v: None if v in ("None", "") else float(v), default=None)
         else:
             p.add_argument(f"--{f.name}", type=str, default=default)
-    for name in IGNORED_FLAGS:
+    for name in ignored_flags:
         p.add_argument(f"--{name}", type=str, default=None, nargs="?", const="True")
     ns, unknown = p.parse_known_args(argv)
     d = vars(ns)
-    ignored = {k: d.pop(k) for k in IGNORED_FLAGS if k in d}
+    ignored = {k: d.pop(k) for k in ignored_flags if k in d}
     # unknown flags: keep "--name value" pairs for the record, never crash
     i = 0
     while i < len(unknown):
@@ -148,12 +233,37 @@ def parse_args(argv=None) -> GRPOArguments:
             i += 2 if val is not unknown[i] and i + 1 < len(unknown) and not unknown[i + 1].startswith("--") else 1
         else:
             i += 1
-    if d.get("epsilon_high") in (None, "None", ""):
-        d["epsilon_high"] = None
-    elif not isinstance(d["epsilon_high"], float):
-        d["epsilon_high"] = float(d["epsilon_high"])
-    a = GRPOArguments(**d)
+    a = cls(**d)
     a.ignored = {k: v for k, v in ignored.items() if v is not None}
+    return a
+
+
+def _check_lora(a):
+    """the reference's own checks (train_grpo.py:76-93, train_sft.py:88-108) + what this engine's LoRA covers"""
+    if a.lora_enable and not a.freeze_llm:
+        raise ValueError("If `lora_enable` is True, `freeze_llm` must also be True.")
+    if a.vision_lora and not a.lora_enable:
+        raise ValueError("`vision_lora` needs `lora_enable`.")
+    if a.vision_lora and not a.freeze_vision_tower:
+        raise ValueError("If `vision_lora` is True, `freeze_vision_tower` must also be True.")
+    if a.lora_enable:
+        if a.vision_lora or a.use_dora or a.lora_bias != "none" or a.bits != 16:
+            raise NotImplementedError("LoRA on this engine: adapters on the LM's linear layers, bias none, 16-bit base weights "
+                                      "(--vision_lora / --use_dora / --lora_bias / --bits 4|8 are not built)")
+        import ast
+        ex = ast.literal_eval(a.lora_namespan_exclude) if a.lora_namespan_exclude else []
+        if not {"lm_head", "embed_tokens"} <= set(ex):
+            raise NotImplementedError("LoRA on this engine leaves lm_head and embed_tokens without adapters: pass "
+                                      "--lora_namespan_exclude \"['lm_head', 'embed_tokens']\" (the shipped recipe's value)")
+
+
+def parse_args(argv=None) -> GRPOArguments:
+    a = _parse(GRPOArguments, argv, IGNORED_FLAGS)
+    if a.epsilon_high in (None, "None", ""):
+        a.epsilon_high = None
+    elif not isinstance(a.epsilon_high, float):
+        a.epsilon_high = float(a.epsilon_high)
+    _check_lora(a)
     if a.grad_exchange_dtype not in ("fp32", "bf16"):
         raise ValueError(f"--grad_exchange_dtype must be fp32 or bf16, got {a.grad_exchange_dtype}")
     if a.loss_norm_unit not in ("per_device_batch", "rank"):

@@ -106,7 +106,7 @@ class Trainer:
     """Training forward / backward / optimiser step on an Engine (shares its stream and workspaces)."""
     KEEP_LOGITS_BYTES = 8 << 30      # forward() keeps a prompt group's fp32 logits for backward() up to this size
 
-    def __init__(self, engine: Engine, text: Params, grad_exchange="fp32", vision_trainer=None, train_lm=True):
+    def __init__(self, engine: Engine, text: Params, grad_exchange="fp32", vision_trainer=None, train_lm=True, lora=None):
         """grad_exchange: wire format of the data-parallel gradient all-reduce.  "fp32" (default) exchanges the fp32 arena as it
         is (30.5 GB per step at 7B: the exact mean of the ranks' fp32 gradients).  "bf16" rounds every bucket to bfloat16 on the
         way out, sums in bfloat16 on the wire and widens the result back into the arena: 15.2 GB per step -- the figure of the
@@ -115,10 +115,12 @@ class Trainer:
         vision_trainer: a train_vision.VisionTrainer when the vision tower and / or the merger train (--freeze_vision_tower False /
         --freeze_merger False): forward() then runs the tower with saved activations from the patch rows it is handed, backward() hands
         the input gradient at the video-token rows down to it, and optimizer_step() clips and updates both parameter sets together.
-        train_lm=False (--freeze_llm True; needs a vision_trainer): the LM's backward computes input gradients only -- no weight
+        train_lm=False (--freeze_llm True; needs a vision_trainer or LoRA adapters): the LM's backward computes input gradients only -- no weight
         gradients, no masters or moments for the LM -- and the optimiser step covers the vision tensors alone."""
-        if not train_lm and vision_trainer is None:
-            raise ValueError("Trainer(train_lm=False) without a vision_trainer: nothing to train")
+        if not train_lm and vision_trainer is None and lora is None:
+            raise ValueError("Trainer(train_lm=False) without a vision_trainer or LoRA adapters: nothing to train")
+        if lora is not None and train_lm:
+            raise ValueError("LoRA adapters go on a frozen LM (train_lm=False), as the reference requires (train_sft.py:88-89)")
         if grad_exchange not in ("fp32", "bf16"):
             raise ValueError(f"grad_exchange must be fp32 or bf16, got {grad_exchange!r}")
         self.eng = engine
@@ -127,6 +129,7 @@ class Trainer:
         self.state = TrainState(text, engine.device, trainable=self.train_lm)
         self.grad_exchange = grad_exchange
         self.vis = vision_trainer
+        self.lora = lora          # lora.LoraTrainer: adapters on the LM's linear layers (the LM itself frozen)
         self._wire = {}           # bf16 mirrors of the gradient arenas (allocated at the first bf16 exchange)
         self._saved = None
         self._works = {}          # bucket key -> in-flight all-reduce of this optimiser step
@@ -385,9 +388,12 @@ class Trainer:
 
     # ------------------------------------------------------------------ optimiser step
     @_on_stream
-    def optimizer_step(self, lr, weight_decay=0.01, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_norm=1.0, grad_scale=1.0):
+    def optimizer_step(self, lr, weight_decay=0.01, beta1=0.9, beta2=0.999, eps=1e-8, max_grad_norm=1.0, grad_scale=1.0,
+                       vision_lr=None, merger_lr=None):
         """All-reduce (mean) the gradients over ranks, clip by global norm, AdamW on the fp32 masters, re-emit bf16 copies,
-        zero the gradients.  grad_scale = 1 / (gradient accumulation count).  Returns the pre-clip global norm (0-d tensor)."""
+        zero the gradients.  grad_scale = 1 / (gradient accumulation count).  Returns the pre-clip global norm (0-d tensor).
+        vision_lr / merger_lr: the SFT trainer's parameter groups (sft_trainer.py:50-110 of the reference: names with "visual" and
+        without "merger" / names with "merger"); None = the common lr."""
         eng, st, W = self.eng, self.state, self.text
         if st.tied and self.train_lm:
             st.grad["embed"].add_(st.grad["lm_head"])        # one shared parameter (Qwen2.5-VL-3B)
@@ -420,6 +426,10 @@ class Trainer:
                 g, m, v = gs.grad[name], gs.m[name], gs.v[name]
                 wd = weight_decay if gs.decay[name] else 0.0
                 kind = gs.kind[name]
+                lr_all = lr
+                if g_ > 0 and groups[g_][0] is getattr(self.vis, "state", None):
+                    group_lr = merger_lr if name in ("fc1_w", "fc2_w", "ln_q", "fc1_b", "fc2_b") else vision_lr
+                    lr = lr_all if group_lr is None else group_lr
                 if kind == "mat":
                     n, kp = GW.shape[name]
                     kt, npad = GW.shape[name + "_t"]
@@ -437,6 +447,7 @@ class Trainer:
                 else:
                     lib.call("vr2_adamw", p, g, m, v, 1, p.numel(), lr, beta1, beta2, eps, wd, st.step_count, st.coef, None, 0, None, 0,
                              None, 0, eng.s)
+                lr = lr_all
         if self.vis is not None:
             self.vis.state.zero_grad()
         st.zero_grad()

@@ -216,6 +216,14 @@ int vr2_swiglu_bwd(const void* gu_bf16, int64_t ldg, const void* dact_bf16, int6
 int vr2_gelu_fwd(const void* z_f32, int64_t ldz, void* h_bf16, int64_t ldh, int64_t T, int64_t N, void* stream);
 int vr2_gelu_bwd(const void* z_f32, int64_t ldz, const void* dh_bf16, int64_t ldd, void* dz_bf16, int64_t ldo, int64_t T, int64_t N,
                  void* stream);
+/* Dropout of the LoRA branch's input (peft lora.Linear.forward: lora_dropout(x), torch.nn.Dropout semantics: kept elements scaled by
+ * 1 / (1 - p)); keep(t, k) is a pure function of (seed, salt, t, k), so vr2_dropout_add redraws the mask in the backward pass:
+ * dst[t][k] += keep ? g[t][k] / (1 - p) : 0, dst fp32 or bf16.  Replaces torch.nn.Dropout inside peft's LoRA layers as configured
+ * by /root/reference/train/src/train/train_sft.py:155-161 (lora_dropout) */
+int vr2_dropout_bf16(const void* x_bf16, int64_t ldx, void* out_bf16, int64_t ldo, int64_t T, int64_t K, float p, uint32_t seed,
+                     uint32_t salt, void* stream);
+int vr2_dropout_add(const void* g_f32, int64_t ldg, void* dst, int64_t ldd, int dst_is_bf16, int64_t T, int64_t K, float p,
+                    uint32_t seed, uint32_t salt, void* stream);
 /* RMSNorm backward: dx (+)= d/dx of rmsnorm(x)*w against dy; dw += column sums (rinv = per-row scratch [M]); dx_bf16: optional
  * bf16 copy of the final dx rows (what the next dgrad / wgrad GEMMs read) */
 int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32, const void* dy_f32, int64_t ldy, void* dx_f32,

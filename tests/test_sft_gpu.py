@@ -46,7 +46,7 @@ def _oracle_step(ocfg, w, rows, trainable, lora=None, extra_params=()):
         total = total + nll / n
     if any(v.requires_grad for v in wt.values()) or lora is not None:
         total.backward()
-    return float(total), {k: v.grad for k, v in wt.items() if v.requires_grad and v.grad is not None}
+    return float(total.detach()), {k: v.grad for k, v in wt.items() if v.requires_grad and v.grad is not None}
 
 
 def _trainer(ocfg, seed, argv, lora=None):
@@ -99,7 +99,7 @@ def test_sft_step_schedule_accumulation_and_parameter_groups():
     assert abs(o0["loss"] - 0.5 * (l_video + l_text)) < 2e-3 * abs(o0["loss"])
     o1 = tr.step([[0], [1]], [[rows[0]], [rows[1]]])
     mult = cosine_lr(1.0, 1, 3, 1)
-    assert mult == 1.0 and abs(o1["metrics"]["learning_rate"] - 1e-3) < 1e-12 and o1["metrics"]["grad_norm"] > 0
+    assert mult == 1.0 and abs(o1["metrics"]["learning_rate"] - 1e-3) < 1e-9 and o1["metrics"]["grad_norm"] > 0
     st, vs = tr.updater.state, tr.updater.vis.state
 
     def moved(cur, old):
@@ -110,3 +110,170 @@ def test_sft_step_schedule_accumulation_and_parameter_groups():
     assert abs(moved(vs.master["b0.qkv_w"], before["b0.qkv_w"]) - 2e-4) < 4e-6
     assert abs(moved(vs.master["fc2_w"], before["fc2_w"]) - 5e-4) < 1e-5
     assert tr.global_step == 2 and tr.num_input_tokens_seen == 2 * (len(rows[0]["input_ids"]) + len(rows[1]["input_ids"]))
+
+
+# ------------------------------------------------------------------------------------------------ LoRA (the shipped SFT recipe)
+def test_dropout_kernels_share_one_mask_and_keep_the_expected_share():
+    from video_r2_amd import lib
+    dev = "cuda:0"
+    T, K, p = 96, 1024, 0.25
+    s = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(T, K, device=dev).to(torch.bfloat16)
+    out, again, other = (torch.empty_like(x) for _ in range(3))
+    lib.call("vr2_dropout_bf16", x, K, out, K, T, K, p, 7, 11, s)
+    lib.call("vr2_dropout_bf16", x, K, again, K, T, K, p, 7, 11, s)
+    lib.call("vr2_dropout_bf16", x, K, other, K, T, K, p, 7, 12, s)
+    torch.cuda.synchronize()
+    keep = out != 0
+    assert torch.equal(out, again) and not torch.equal(out != 0, other != 0)                 # a pure function of (seed, salt, t, k)
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+    assert torch.equal(out[keep], (x.float() / (1 - p)).to(torch.bfloat16)[keep])               # torch.nn.Dropout's scaling
+    rows, cols = keep.float().mean(1), keep.float().mean(0)
+    assert rows.min() > 0.65 and rows.max() < 0.85 and cols.min() > 0.5 and cols.max() < 0.95  # no dead rows / columns
+    g = torch.randn(T, K, device=dev)
+    d32, d16 = torch.ones(T, K, device=dev), torch.ones(T, K, device=dev).to(torch.bfloat16)
+    lib.call("vr2_dropout_add", g, K, d32, K, 0, T, K, p, 7, 11, s)
+    lib.call("vr2_dropout_add", g, K, d16, K, 1, T, K, p, 7, 11, s)
+    torch.cuda.synchronize()
+    want = 1.0 + torch.where(keep, g / (1 - p), torch.zeros_like(g))
+    assert torch.allclose(d32, want, atol=1e-6) and torch.equal(d16, want.to(torch.bfloat16))    # the backward's mask IS the forward's
+    full = torch.empty_like(x)
+    lib.call("vr2_dropout_bf16", x, K, full, K, T, K, 0.0, 7, 11, s)
+    torch.cuda.synchronize()
+    assert torch.equal(full, x)                                                                   # p = 0 keeps everything, unscaled
+
+
+def _lora_pair(ocfg, m, w, r, alpha, p, b_std):
+    """the same adapters on both sides: oracle tensors (bf16-representable) loaded into the engine in peft's layout"""
+    from video_r2_amd.lora import LoraTrainer
+    lo_o = osft.LoraOracle(w, ocfg.text.num_hidden_layers, r, alpha, seed=3, b_std=b_std)
+    for d in (lo_o.A, lo_o.B):
+        for k in d:
+            d[k] = d[k].detach().to(torch.bfloat16).float().requires_grad_(True)
+    lo_e = LoraTrainer(m.engine, m.text, rank=r, alpha=alpha, dropout=p, seed=5)
+    sd = {}
+    for k in lo_o.A:
+        sd[f"base_model.model.{k}.lora_A.weight"] = lo_o.A[k].detach()
+        sd[f"base_model.model.{k}.lora_B.weight"] = lo_o.B[k].detach()
+    lo_e.load_adapter_state_dict(sd)
+    return lo_o, lo_e
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_lora_sft_loss_and_adapter_gradients_vs_autograd(p):
+    """base + B A (dropout(x)) * alpha / r on every LM linear layer, B != 0, against autograd through the oracle with the engine's own
+    dropout draws; the frozen LM holds no gradients; peft-layout round trip; one optimiser step changes only the adapters"""
+    from video_r2_amd import lib
+    from video_r2_amd.lora import SITES
+    from video_r2_amd.model import VideoR2Model
+    from video_r2_amd.sft import QwenSFTTrainer
+    ocfg = om.cfg_tiny(2)
+    w = om.make_weights(ocfg, seed=77)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), w, device="cuda:0")
+    args = params.parse_sft_args(["--freeze_llm", "True", "--freeze_vision_tower", "True", "--freeze_merger", "True", "--lora_enable", "True",
+                                  "--lora_rank", "8", "--lora_alpha", "16", "--lora_dropout", str(p), "--lora_namespan_exclude", "['lm_head', 'embed_tokens']",
+                                  "--learning_rate", "1e-3", "--weight_decay", "0.0"])
+    lo_o, lo_e = _lora_pair(ocfg, m, w, 8, 16, p, 0.02)
+    assert lo_e.n_params() == sum(a.numel() for a in lo_o.A.values()) + sum(b.numel() for b in lo_o.B.values())
+    tr = QwenSFTTrainer(m, args, list(range(4)), lambda ex: ex, lora=lo_e)
+    rows = _rows(m.cfg, 77)
+    n_mb = sum(int((r["labels"][1:] != -100).sum()) for r in rows)
+    masks_of = []                                          # per row: the masks its forward will draw (forward ids 1, 2 in order)
+    s = torch.cuda.current_stream().cuda_stream
+    site_mods = {"qkv": ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), "o": ("self_attn.o_proj",),
+                 "gu": ("mlp.gate_proj", "mlp.up_proj"), "down": ("mlp.down_proj",)}
+    for fid, r in enumerate(rows, start=1):
+        T = len(r["input_ids"])
+        mk = {}
+        for l in range(ocfg.text.num_hidden_layers):
+            for site in SITES:
+                K = lo_e.W.shape[f"l{l}.{site}.A"][1]
+                ones, out = torch.ones(T, K, device="cuda:0", dtype=torch.bfloat16), torch.empty(T, K, device="cuda:0", dtype=torch.bfloat16)
+                lib.call("vr2_dropout_bf16", ones, K, out, K, T, K, p, lo_e.seed & 0xFFFFFFFF, lo_e._salt(fid, l, site), s)
+                for mod in site_mods[site]:
+                    fin = lo_o.A[f"model.layers.{l}.{mod}"].shape[1]
+                    mk[f"model.layers.{l}.{mod}"] = (out != 0).float().cpu()[None, :, :fin]
+        masks_of.append(mk)
+    torch.cuda.synchronize()
+    parts = [tr._row(r, 1.0 / n_mb, last=(i == len(rows) - 1)) for i, r in enumerate(rows)]
+    m.engine.sync()
+    loss = sum(float(nll.item()) for nll, _ in parts) / n_mb
+    assert tr.updater.state.master == {} and tr.updater.state.arena.numel() == 0         # the LM is frozen: adapters only
+
+    def hooks(r):
+        lo_o.set_dropout(masks_of[[id(x) for x in rows].index(id(r))] if p > 0 else {}, p)
+        return lo_o.hooks()
+    o_loss, _ = _oracle_step(ocfg, w, rows, lambda k: False, lora=hooks)
+    assert abs(loss - o_loss) < 2e-3 * abs(o_loss), (loss, o_loss)
+    lo_e.finish_grads()
+    torch.cuda.synchronize()
+    worst = {}
+    for l in range(ocfg.text.num_hidden_layers):
+        for site in SITES:
+            gA, gB = lo_e.grad[(l, site, "A")], lo_e.grad[(l, site, "B")]
+            assert float((gA * (1 - lo_e.mask[(l, site, "A")])).abs().max()) == 0.0 and float((gB * (1 - lo_e.mask[(l, site, "B")])).abs().max()) == 0.0
+            for j, (mod, fin, rws) in enumerate(lo_e.layout[site]):
+                name = f"model.layers.{l}.{mod}"
+                ga = gA[j * lo_e.rp:j * lo_e.rp + 8, :fin].cpu()
+                gb = gB[rws][:, j * lo_e.rp:j * lo_e.rp + 8].cpu()
+                for got, ref, kind in ((ga, lo_o.A[name].grad, "A"), (gb, lo_o.B[name].grad, "B")):
+                    worst[name + "." + kind] = (got - ref).norm().item() / max(ref.norm().item(), 1e-12)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("lora p=%.2f: loss %.5f vs %.5f; max rel grad err %.3e (median %.3e); worst %s"
+          % (p, loss, o_loss, max(worst.values()), float(np.median(list(worst.values()))), ", ".join("%s %.2e" % kv for kv in top)))
+    assert max(worst.values()) < 3e-2, top
+    # peft layout round trip and the merge: W + s B A reproduces the adapted forward (dropout is a training-time perturbation)
+    sd = lo_e.adapter_state_dict()
+    assert set(sd) == {f"base_model.model.{k}.lora_{ab}.weight" for k in lo_o.A for ab in "AB"}
+    assert torch.equal(sd["base_model.model.model.layers.1.mlp.up_proj.lora_B.weight"], lo_o.B["model.layers.1.mlp.up_proj"].detach())
+    before_lm = {k: m.text[k].clone() for k in ("l0.qkv_w", "l1.down_w", "lm_head", "embed")}
+    a0 = lo_e.master[(0, "qkv", "A")].clone()
+    gn = tr.updater.optimizer_step(lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    m.engine.sync()
+    assert gn.item() > 0 and not torch.equal(lo_e.master[(0, "qkv", "A")], a0) and float(lo_e.arena.abs().max()) == 0.0
+    assert all(torch.equal(m.text[k], v) for k, v in before_lm.items())
+    assert float((lo_e.master[(0, "qkv", "B")] * (1 - lo_e.mask[(0, "qkv", "B")])).abs().max()) == 0.0      # off-block entries stay zero
+
+
+def test_lora_with_zero_b_is_the_base_model_bit_for_bit_and_merge_matches_the_adapted_forward(tmp_path):
+    from video_r2_amd.lora import LoraTrainer, merged_state_dict
+    from video_r2_amd.model import VideoR2Model
+    from video_r2_amd.train import Trainer
+    ocfg = om.cfg_tiny(2)
+    w = om.make_weights(ocfg, seed=78)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), w, device="cuda:0")
+    r = _rows(m.cfg, 78)[0]
+    from video_r2_amd.sft import split_supervised
+    prompt, comp, mask = split_supervised(r["input_ids"], r["labels"])
+    eng = m.engine
+    (emb, plan), = eng.encode_videos([dict(frames_u8=r["videos"][0][0], resize_to=None)], per_prompt=[1])
+    emb = emb.clone()
+    comp_d = torch.from_numpy(comp[None]).cuda()
+    vis_tr = None
+    base = Trainer(eng, m.text)
+    lp_base = base.forward(prompt, emb, plan, [1.0], comp_d, 1.0).clone()
+    del base
+    lo = LoraTrainer(eng, m.text, rank=8, alpha=16, dropout=0.1, seed=9)          # fresh adapters: B = 0
+    tr = Trainer(eng, m.text, train_lm=False, lora=lo)
+    lp0 = tr.forward(prompt, emb, plan, [1.0], comp_d, 1.0).clone()
+    eng.sync()
+    assert torch.equal(lp0, lp_base)                                               # exact zeros joined in fp32: the base model, bit for bit
+    # non-zero B, no dropout: the adapted forward == the forward of the merged weights (up to the merge's bf16 rounding of W + s B A)
+    lo_o, lo2 = _lora_pair(ocfg, m, w, 8, 16, 0.0, 0.02)
+    tr2 = Trainer(eng, m.text, train_lm=False, lora=lo2)
+    lp_ad = tr2.forward(prompt, emb, plan, [1.0], comp_d, 1.0).clone()
+    lo2.save_adapter(str(tmp_path / "adapter"), base_model_name_or_path="base")
+    from safetensors.torch import load_file
+    import json
+    cfg_json = json.loads((tmp_path / "adapter" / "adapter_config.json").read_text())
+    assert cfg_json["r"] == 8 and cfg_json["lora_alpha"] == 16 and cfg_json["peft_type"] == "LORA" and len(cfg_json["target_modules"]) == 14
+    merged = merged_state_dict(w, load_file(str(tmp_path / "adapter" / "adapter_model.safetensors")), cfg_json["lora_alpha"] / cfg_json["r"])
+    ref = lo_o.merged(w)
+    for k in ("model.layers.0.self_attn.k_proj.weight", "model.layers.1.mlp.gate_proj.weight"):
+        assert torch.allclose(merged[k].float(), ref[k], atol=1e-6)
+    m2 = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), merged, device="cuda:0")
+    (emb2, plan2), = m2.engine.encode_videos([dict(frames_u8=r["videos"][0][0], resize_to=None)], per_prompt=[1])
+    lp_m = Trainer(m2.engine, m2.text).forward(prompt, emb2.clone(), plan2, [1.0], comp_d, 1.0).clone()
+    m2.engine.sync()
+    d = rel_err(lp_ad.cpu().numpy(), lp_m.cpu().numpy())
+    assert d.max() < 2e-2 and np.median(d) < 3e-3 and not torch.equal(lp_ad, lp_base)

@@ -74,6 +74,56 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
   *reinterpret_cast<bf16x4*>(dz + (long)t * ldo + i) = o;
 }
 
+// ------------------------------------------------------------------ dropout on the LoRA branch's input (peft lora.Linear: lora_dropout(x))
+// keep(t, k) is a pure function of (seed, salt, t, k) -- a 32-bit mix of the element's coordinates, compared with p * 2^32 -- so the
+// backward pass redraws the forward's mask from the same four numbers instead of keeping a T x K mask per adapted layer.
+__device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned salt, unsigned t, unsigned k) {
+  unsigned h = seed ^ (salt * 0x9E3779B9u);
+  h ^= t + 0x7F4A7C15u + (h << 6) + (h >> 2);
+  h *= 0x85EBCA6Bu; h ^= h >> 13;
+  h ^= k + 0x165667B1u + (h << 6) + (h >> 2);
+  h *= 0xC2B2AE35u; h ^= h >> 16;
+  h *= 0x27D4EB2Fu; h ^= h >> 15;
+  return h;
+}
+
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16* __restrict__ x, long ldx, bf16* __restrict__ out, long ldo, int K,
+                                                           unsigned thresh, float inv_keep, unsigned seed, unsigned salt) {
+  const int t = blockIdx.y;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= K) return;
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(x + (long)t * ldx + i);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (drop_hash(seed, salt, (unsigned)t, (unsigned)(i + j)) >= thresh) ? f2bf(bf2f(v[j]) * inv_keep) : f2bf(0.f);
+  *reinterpret_cast<bf16x4*>(out + (long)t * ldo + i) = o;
+}
+
+// dst (+)= keep ? g / (1 - p) : 0  -- the adapter branch's share of the input gradient, through the same mask; dst fp32 or bf16
+template <bool DST_BF16>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ g, long ldg, void* __restrict__ dst, long ldd, int K,
+                                                          unsigned thresh, float inv_keep, unsigned seed, unsigned salt) {
+  const int t = blockIdx.y;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= K) return;
+  const float4 v = *reinterpret_cast<const float4*>(g + (long)t * ldg + i);
+  const float a[4] = {v.x, v.y, v.z, v.w};
+  float add[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) add[j] = (drop_hash(seed, salt, (unsigned)t, (unsigned)(i + j)) >= thresh) ? a[j] * inv_keep : 0.f;
+  if constexpr (DST_BF16) {
+    bf16* d = reinterpret_cast<bf16*>(dst) + (long)t * ldd + i;
+    const bf16x4 old = *reinterpret_cast<const bf16x4*>(d);
+    bf16x4 o = {f2bf(bf2f(old[0]) + add[0]), f2bf(bf2f(old[1]) + add[1]), f2bf(bf2f(old[2]) + add[2]), f2bf(bf2f(old[3]) + add[3])};
+    *reinterpret_cast<bf16x4*>(d) = o;
+  } else {
+    float* d = reinterpret_cast<float*>(dst) + (long)t * ldd + i;
+    float4 old = *reinterpret_cast<const float4*>(d);
+    old.x += add[0]; old.y += add[1]; old.z += add[2]; old.w += add[3];
+    *reinterpret_cast<float4*>(d) = old;
+  }
+}
+
 // ------------------------------------------------------------------ RMSNorm backward (row part)
 // y = x * inv * w, inv = rsqrt(mean(x^2) + eps).  dx_out[m][:] (+)= inv * (w o dy) - x * inv^3 / H * sum(x o w o dy)
 // rinv[m] = inv is also written (the weight-gradient column pass needs it).
@@ -308,6 +358,33 @@ extern "C" int vr2_gelu_bwd(const void* z_f32, int64_t ldz, const void* dh_bf16,
   hipLaunchKernelGGL(gelu_bwd_kernel, grid, dim3(256), 0, STREAM, (const float*)z_f32, (long)ldz, (const bf16*)dh_bf16, (long)ldd,
                      (bf16*)dz_bf16, (long)ldo, (int)N);
   return vr2_check_launch("vr2_gelu_bwd");
+}
+
+static unsigned drop_threshold(float p) {   // keep iff hash >= p * 2^32
+  const double t = (double)p * 4294967296.0;
+  return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+}
+
+extern "C" int vr2_dropout_bf16(const void* x_bf16, int64_t ldx, void* out_bf16, int64_t ldo, int64_t T, int64_t K, float p,
+                                uint32_t seed, uint32_t salt, void* stream) {
+  VR2_REQUIRE(T >= 1 && K % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= K && ldo >= K && p >= 0.f && p < 1.f, "vr2_dropout_bf16: bad shape");
+  dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned)T);
+  hipLaunchKernelGGL(dropout_bf16_kernel, grid, dim3(256), 0, STREAM, (const bf16*)x_bf16, (long)ldx, (bf16*)out_bf16, (long)ldo, (int)K,
+                     drop_threshold(p), 1.0f / (1.0f - p), (unsigned)seed, (unsigned)salt);
+  return vr2_check_launch("vr2_dropout_bf16");
+}
+
+extern "C" int vr2_dropout_add(const void* g_f32, int64_t ldg, void* dst, int64_t ldd, int dst_is_bf16, int64_t T, int64_t K, float p,
+                               uint32_t seed, uint32_t salt, void* stream) {
+  VR2_REQUIRE(T >= 1 && K % 4 == 0 && ldg % 4 == 0 && ldd % 4 == 0 && ldg >= K && ldd >= K && p >= 0.f && p < 1.f, "vr2_dropout_add: bad shape");
+  dim3 grid((unsigned)((K / 4 + 255) / 256), (unsigned)T);
+  if (dst_is_bf16)
+    hipLaunchKernelGGL(dropout_add_kernel<true>, grid, dim3(256), 0, STREAM, (const float*)g_f32, (long)ldg, dst, (long)ldd, (int)K,
+                       drop_threshold(p), 1.0f / (1.0f - p), (unsigned)seed, (unsigned)salt);
+  else
+    hipLaunchKernelGGL(dropout_add_kernel<false>, grid, dim3(256), 0, STREAM, (const float*)g_f32, (long)ldg, dst, (long)ldd, (int)K,
+                       drop_threshold(p), 1.0f / (1.0f - p), (unsigned)seed, (unsigned)salt);
+  return vr2_check_launch("vr2_dropout_add");
 }
 
 extern "C" int vr2_rmsnorm_bwd(const void* x_f32, int64_t ldx, const void* w_f32, const void* dy_f32, int64_t ldy, void* dx_f32,

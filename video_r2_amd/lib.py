@@ -14,7 +14,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "vr2.h")
 LIBPATH = os.environ.get("VR2_LIBPATH") or os.path.join(HERE, "libvr2.so")     # (the override: A/B runs of two builds on one box)
 
 _CT = {
-    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "uint32_t": ctypes.c_uint32, "float": ctypes.c_float,
 }
 
 

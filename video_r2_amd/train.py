@@ -175,19 +175,19 @@ class Trainer:
         self._works[key] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
         if self._watch is None:
             self._watch = vdist.ExchangeWatch()
-        self._watch.add({"head": "head (lm_head + final norm)", "embed": "embedding rows", "vision": "vision tower / merger"}.get(key, f"layer {key}"),
+        self._watch.add({"head": "head (lm_head + final norm)", "embed": "embedding rows", "vision": "vision tower / merger", "lora": "LoRA adapters"}.get(key, f"layer {key}"),
                         self._works[key], buf.numel() * buf.element_size())
 
     def _bucket(self, key):
         """(arena, first element, one-past-last element) of a gradient bucket: one of the LM's backward stages, or the vision side's"""
-        for st in ([self.state] + ([self.vis.state] if self.vis is not None else [])):
+        for st in ([self.state] + ([self.vis.state] if self.vis is not None else []) + ([self.lora] if self.lora is not None else [])):
             for k, first, last in st.buckets:
                 if k == key:
                     return st.arena, first, last
         raise KeyError(key)
 
     def _bucket_keys(self):
-        return [k for k, _, _ in self.state.buckets] + (["vision"] if self.vis is not None else [])
+        return [k for k, _, _ in self.state.buckets] + (["vision"] if self.vis is not None else []) + (["lora"] if self.lora is not None else [])
 
     # ------------------------------------------------------------------ forward with saved activations
     @_on_stream
@@ -214,12 +214,18 @@ class Trainer:
         b = eng.buf
         x, cos, sin = eng.unified_inputs(W, u, video_embeds, plan, "t")
         kwork = _i32(vp.key_work(S, G, C, group=t.group, lens=None if lay is None else u["seq_len"]), eng.device)
+        lo = self.lora
+        fid = lo.begin_forward() if lo is not None else 0
+        xk = lo.extra_k("gu") if lo is not None else 0      # LoRA: the gate/up adapters' t columns ride behind the normed row
         sv = dict(x_in=b("t.x_in", (L, T, H), torch.float32), xn1=b("t.xn1", (L, T, H), torch.bfloat16),
                   q=b("t.q", (L, T, nq * hd), torch.bfloat16), k=b("t.k", (L, T, nkv * hd), torch.bfloat16),
                   v=b("t.v", (L, T, nkv * hd), torch.bfloat16), att=b("t.att", (L, T, nq * hd), torch.bfloat16),
                   lse=b("t.lse", (L, T, nq), torch.float32), x_mid=b("t.x_mid", (L, T, H), torch.float32),
-                  xn2=b("t.xn2", (L, T, H), torch.bfloat16), gu=b("t.gu", (L, T, 2 * I16), torch.bfloat16),
+                  xn2=b("t.xn2", (L, T, H + xk), torch.bfloat16), gu=b("t.gu", (L, T, 2 * I16), torch.bfloat16),
                   act=b("t.acts", (L, T, I16), torch.bfloat16))   # SwiGLU output kept for the down-projection wgrad (9.8 GB at 7B)
+        if lo is not None:
+            sv.update(t_qkv=b("t.lora_qkv", (L, T, lo.extra_k("qkv")), torch.bfloat16), t_o=b("t.lora_o", (L, T, lo.extra_k("o")), torch.bfloat16),
+                      t_down=b("t.lora_down", (L, T, lo.extra_k("down")), torch.bfloat16))
         qkv32 = b("t.qkv32", (T, nqkv), torch.float32)
         scale = hd ** -0.5
         for l in range(L):
@@ -228,20 +234,33 @@ class Trainer:
             xn1 = sv["xn1"][l]
             eng._norm(x, W[f"l{l}.ln1"], xn1, T, H, t.rms_norm_eps)
             self._gemm(xn1, f"l{l}.qkv_w", W[f"l{l}.qkv_b"], qkv32, T, EPI_F32)
+            if lo is not None:
+                lo.project(fid, l, "qkv", xn1, sv["t_qkv"][l], T)
+                lo.join(l, "qkv", sv["t_qkv"][l], qkv32, T)
             q, k, v = sv["q"][l], sv["k"][l], sv["v"][l]
             lib.call("vr2_rope_qkv", qkv32, qkv32.stride(0), cos, sin, T, nq, nkv, hd, q, q.stride(0), k, v, k.stride(0), 0, eng.s)
             att = sv["att"][l]
             lib.call("vr2_attn_tok", d_work, d_work.shape[0], q, q.stride(0), k, v, k, v, k.stride(0), att, att.stride(0), nq,
                      t.group, hd, scale, sv["lse"][l], eng.s)
             self._gemm(att, f"l{l}.o_w", None, x, T, EPI_ADD_F32)
+            if lo is not None:
+                lo.project(fid, l, "o", att, sv["t_o"][l], T)
+                lo.join(l, "o", sv["t_o"][l], x, T)
             sv["x_mid"][l].copy_(x)
             xn2 = sv["xn2"][l]
             eng._norm(x, W[f"l{l}.ln2"], xn2, T, H, t.rms_norm_eps)
             gu = sv["gu"][l]
             ngu, kgu = W.shape[f"l{l}.gu_w"]
-            lib.call("vr2_gemm_swiglu_save", xn2, xn2.stride(0), W[f"l{l}.gu_w"], None, act, act.stride(0), gu, gu.stride(0), T,
+            gu_w = W[f"l{l}.gu_w"]
+            if lo is not None:                 # [xn2 | t] x [W | s B]^T: the adapters join before the SwiGLU epilogue
+                lo.project(fid, l, "gu", xn2[:, :H], xn2[:, H:], T)
+                gu_w, (ngu, kgu) = lo.W[f"l{l}.gu_we"], lo.W.shape[f"l{l}.gu_we"]
+            lib.call("vr2_gemm_swiglu_save", xn2, xn2.stride(0), gu_w, None, act, act.stride(0), gu, gu.stride(0), T,
                      ngu, kgu, eng.s)
             self._gemm(act, f"l{l}.down_w", None, x, T, EPI_ADD_F32)
+            if lo is not None:
+                lo.project(fid, l, "down", act, sv["t_down"][l], T)
+                lo.join(l, "down", sv["t_down"][l], x, T)
         # log-prob head: row (g, j) is predicted by the prompt's last row (j == 0) or completion row (g, j-1)
         hs = b("t.hs", (R, H), torch.float32)
         torch.index_select(x, 0, u["pred"], out=hs)
@@ -253,7 +272,7 @@ class Trainer:
         keep = R * V * 4 <= self.KEEP_LOGITS_BYTES
         lg_all = b("t.logits", (R, V), torch.float32) if keep else None
         eng.head_logps(W, hs, u, temperature, logp, hn=hn, logits_all=lg_all, lse_out=lse_out, allow_f8=False)
-        self._saved = dict(logits=lg_all, sv=sv, S=S, G=G, C=C, T=T, R=R, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
+        self._saved = dict(fid=fid, logits=lg_all, sv=sv, S=S, G=G, C=C, T=T, R=R, cos=cos, sin=sin, work=d_work, kwork=kwork, ids=all_ids, hs=hs, hn=hn, tok=tok,
                            lse_out=lse_out, temperature=temperature, has_video=video_embeds is not None, sel=d_sel,
                            vis_dst=(_i32(u["vid_pos"][plan.window_index], eng.device).long()
                                     if (self.vis is not None and vision_rows is not None and plan is not None) else None),
@@ -276,6 +295,7 @@ class Trainer:
         I16 = (I + 15) // 16 * 16
         nqkv = (nq + 2 * nkv) * hd
         S, G, C, T, R, sv = s["S"], s["G"], s["C"], s["T"], s["R"], s["sv"]
+        lo, fid = self.lora, s["fid"]
         b = eng.buf
         dl = dlogp.reshape(-1).to(torch.float32).contiguous()
         if s["sel"] is not None:
@@ -326,16 +346,22 @@ class Trainer:
         for l in reversed(range(L)):
             # ---- MLP
             self._gemm(dxb, f"l{l}.down_w_t", None, dact, T, EPI_BF16)
+            if lo is not None:
+                lo.backward(fid, l, "down", dxb, sv["act"][l], sv["t_down"][l], dact, T)
             gu = sv["gu"][l]
             self._wgrad(dxb, sv["act"][l], f"l{l}.down_w", H, I16, T)
             lib.call("vr2_swiglu_bwd", gu, gu.stride(0), dact, dact.stride(0), dgu, dgu.stride(0), T, I16, eng.s)
             self._gemm(dgu, f"l{l}.gu_w_t", None, dxn, T, EPI_F32)
+            if lo is not None:
+                lo.backward(fid, l, "gu", dgu, sv["xn2"][l][:, :H], sv["xn2"][l][:, H:], dxn, T)
             self._wgrad(dgu, sv["xn2"][l], f"l{l}.gu_w", 2 * I16, H, T)
             lib.call("vr2_rmsnorm_bwd", sv["x_mid"][l], H, W[f"l{l}.ln2"], dxn, H, dx, H, rinv, gr(f"l{l}.ln2"), T, H,
                      t.rms_norm_eps, 1, dxb, dxb.stride(0), eng.s)
             # ---- attention
             self._gemm(dxb, f"l{l}.o_w_t", None, datt, T, EPI_BF16)
             att, q, k, v, lse = sv["att"][l], sv["q"][l], sv["k"][l], sv["v"][l], sv["lse"][l]
+            if lo is not None:
+                lo.backward(fid, l, "o", dxb, att, sv["t_o"][l], datt, T)
             self._wgrad(dxb, att, f"l{l}.o_w", H, nq * hd, T)
             lib.call("vr2_attn_delta", att, datt, att.stride(0), T, nq, hd, lse, rowc, eng.s)
             lib.call("vr2_attn_bwd_dq", s["work"], s["work"].shape[0], q, q.stride(0), k, v, k, v, k.stride(0), datt, rowc, T, dq,
@@ -347,6 +373,8 @@ class Trainer:
             if self.train_lm:
                 lib.call("vr2_colsum_bf16", dqkv, dqkv.stride(0), st.grad[f"l{l}.qkv_b"], T, nqkv, eng.s)
             self._gemm(dqkv, f"l{l}.qkv_w_t", None, dxn, T, EPI_F32)
+            if lo is not None:
+                lo.backward(fid, l, "qkv", dqkv, sv["xn1"][l], sv["t_qkv"][l], dxn, T)
             self._wgrad(dqkv, sv["xn1"][l], f"l{l}.qkv_w", nqkv, H, T)
             lib.call("vr2_rmsnorm_bwd", sv["x_in"][l], H, W[f"l{l}.ln1"], dxn, H, dx, H, rinv, gr(f"l{l}.ln1"), T, H,
                      t.rms_norm_eps, 1, dxb, dxb.stride(0), eng.s)
@@ -365,6 +393,9 @@ class Trainer:
             self.vis.backward(dx.index_select(0, s["vis_dst"]))
             if exchange:
                 self._exchange("vision")
+        if lo is not None and exchange:
+            lo.finish_grads()
+            self._exchange("lora")
         self._saved = None
 
     # ------------------------------------------------------------------ checkpoint resume
@@ -398,6 +429,9 @@ class Trainer:
         if st.tied and self.train_lm:
             st.grad["embed"].add_(st.grad["lm_head"])        # one shared parameter (Qwen2.5-VL-3B)
         world = vdist.world_size()
+        lo = self.lora
+        if lo is not None:
+            lo.finish_grads()
         if world > 1:
             for key in self._bucket_keys():                   # whatever the last backward did not already put on the wire
                 self._exchange(key)
@@ -411,12 +445,16 @@ class Trainer:
         groups = [(st, W)] + ([(self.vis.state, self.vis.W)] if self.vis is not None else [])
         names = [(g_, n_) for g_, (gs, _) in enumerate(groups) for n_ in gs.grad if not (g_ == 0 and st.tied and n_ == "lm_head")]
         slot_f = int(lib.load().vr2_sumsq_slot_floats())
-        if st.sumsq.numel() != len(names) * slot_f:
-            st.sumsq = torch.zeros(len(names) * slot_f, dtype=torch.float32, device=st.sumsq.device)
+        n_slots = len(names) + (len(lo.grad) if lo is not None else 0)
+        if st.sumsq.numel() != n_slots * slot_f:
+            st.sumsq = torch.zeros(n_slots * slot_f, dtype=torch.float32, device=st.sumsq.device)
         for slot, (g_, name) in enumerate(names):   # per-tensor slots of per-block partials, summed in a fixed order: no atomics
             g = groups[g_][0].grad[name]
             lib.call("vr2_sumsq_f32", g, g.numel(), st.sumsq, slot, eng.s)
-        lib.call("vr2_clip_coef", st.sumsq, len(names), float(max_grad_norm if max_grad_norm else 0.0), float(grad_scale), st.coef,
+        if lo is not None:
+            for j, g in enumerate(lo.grad.values()):
+                lib.call("vr2_sumsq_f32", g, g.numel(), st.sumsq, len(names) + j, eng.s)
+        lib.call("vr2_clip_coef", st.sumsq, n_slots, float(max_grad_norm if max_grad_norm else 0.0), float(grad_scale), st.coef,
                  st.gnorm, eng.s)
         st.step_count += 1
         for g_, (gs, GW) in enumerate(groups):
@@ -448,6 +486,12 @@ class Trainer:
                     lib.call("vr2_adamw", p, g, m, v, 1, p.numel(), lr, beta1, beta2, eps, wd, st.step_count, st.coef, None, 0, None, 0,
                              None, 0, eng.s)
                 lr = lr_all
+        if lo is not None:      # the adapters: plain fp32 tensors (weight decay applies, HF's no-decay set is biases and norms)
+            for k, p in lo.master.items():
+                lib.call("vr2_adamw", p, lo.grad[k], lo.m[k], lo.v[k], 1, p.numel(), lr, beta1, beta2, eps, weight_decay, st.step_count, st.coef,
+                         None, 0, None, 0, None, 0, eng.s)
+            lo.refresh()
+            lo.zero_grad()
         if self.vis is not None:
             self.vis.state.zero_grad()
         st.zero_grad()

@@ -6,6 +6,7 @@ import ast
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -144,3 +145,82 @@ def test_train_grpo_sh_trains_checkpoints_and_resumes(tmp_path):
     assert not np.array_equal(sft["visual.merger.mlp.2.weight"].float().numpy(), got6["visual.merger.mlp.2.weight"].float().numpy())
     for k in ("visual.blocks.0.attn.qkv.weight", "model.layers.0.self_attn.o_proj.weight", "lm_head.weight", "model.embed_tokens.weight"):
         assert np.array_equal(sft[k].float().numpy(), got6[k].float().numpy()), k
+
+
+def test_train_sft_sh_lora_recipe_then_merge_then_full_fine_tune(tmp_path):
+    """`bash train/scripts/train_sft.sh` (the reference's launch line, scripts/train_sft.sh:27-66: LoRA on the LM's linear layers,
+    everything else frozen) on a tiny HF-layout model directory and a 6-row dataset (array clips, one still image, one text-only row, a
+    two-answer conversation): adapters in peft's layout + non_lora_state_dict.bin; `merge_lora_weights.py` folds them into an HF
+    directory that loads; a second launch with --lora_enable False trains the LM and the merger, checkpoints and resumes."""
+    import torch
+    from PIL import Image
+    from safetensors.torch import load_file
+    from video_r2_amd.model import VideoR2Model
+    ocfg = om.cfg_tiny(2)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), om.make_weights(ocfg, seed=43), device="cuda:0")
+    model_dir = tmp_path / "base_model"
+    m.save_pretrained(str(model_dir))
+    (model_dir / "generation_config.json").write_text("{}")
+    del m
+    clips = tmp_path / "videos"
+    (clips / "set").mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    rows = []
+    for i in range(4):
+        np.savez(clips / "set" / f"c{i}.npz", frames=rng.integers(0, 256, size=(60, 56, 84, 3), dtype=np.uint8), fps=np.float32(30.0))
+        conv = [{"from": "human", "value": f"<video>\nWhat happens in clip {i}?"}, {"from": "gpt", "value": f"<think>00:01 something</think><answer>{'AB'[i % 2]}</answer>"}]
+        if i == 0:
+            conv += [{"from": "human", "value": "And after that?"}, {"from": "gpt", "value": "Nothing else."}]
+        rows.append({"video": f"set/c{i}.npz", "conversations": conv})
+    Image.fromarray(rng.integers(0, 256, size=(60, 90, 3), dtype=np.uint8)).save(clips / "set" / "p.png")
+    rows.append({"image": "set/p.png", "conversations": [{"from": "human", "value": "<image>\nWhat is shown?"}, {"from": "gpt", "value": "A picture."}]})
+    rows.append({"conversations": [{"from": "human", "value": "Say hello."}, {"from": "gpt", "value": "Hello."}]})
+    data = tmp_path / "sft.json"
+    data.write_text(json.dumps(rows))
+    out_dir = tmp_path / "out_lora"
+    env = dict(os.environ, NUM_DEVICES="1", GLOBAL_BATCH_SIZE="2", BATCH_PER_DEVICE="1", MODEL_NAME=str(model_dir), DATA_PATH=str(data), DATA_FOLDER=str(clips),
+               SUBTITLES_FOLDER=str(tmp_path / "subs"), OUTPUT_DIR=str(out_dir), FPS_MAX_FRAMES="4", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def launch(env_, *flags):
+        r = subprocess.run(["bash", os.path.join(ROOT, "train", "scripts", "train_sft.sh"), *flags], env=env_, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + "\n---- stderr ----\n" + r.stderr[-6000:]
+        return [ast.literal_eval(ln) for ln in r.stdout.splitlines() if ln.startswith("{'step'")], r.stderr
+
+    small = ["--video_min_pixels", "4704", "--video_max_pixels", "4704", "--image_min_pixels", "3136", "--image_max_pixels", "4704", "--lora_rank", "8",
+             "--lora_alpha", "16", "--learning_rate", "1e-3", "--dataloader_num_workers", "2"]
+    steps, err = launch(env, *small)
+    assert [s["step"] for s in steps] == [1, 2, 3], err[-3000:]                       # 6 rows / (1 x 2 accumulated x 1 rank), one epoch
+    assert all(np.isfinite(s["loss"]) and s["loss"] > 0 for s in steps) and steps[0]["learning_rate"] == 0.0 and steps[1]["grad_norm"] > 0
+    assert "Adding LoRA to the model... 14 lora modules" in err and "Trainable parameters:" in err and "1 warm-up step" in err
+    ad = load_file(str(out_dir / "adapter_model.safetensors"))
+    assert len(ad) == 28 and ad["base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"].shape == (8, 512)
+    assert float(ad["base_model.model.model.layers.1.mlp.down_proj.lora_B.weight"].abs().max()) > 0           # B left zero: the adapters trained
+    cfgj = json.loads((out_dir / "adapter_config.json").read_text())
+    assert cfgj["r"] == 8 and cfgj["lora_alpha"] == 16 and cfgj["lora_dropout"] == 0.05 and cfgj["base_model_name_or_path"] == str(model_dir)
+    assert torch.load(str(out_dir / "non_lora_state_dict.bin"), weights_only=True) == {} and (out_dir / "config.json").exists()
+    assert not (out_dir / "model.safetensors").exists()                                  # adapters only, as the reference saves them
+    # merge_lora_weights.py: adapters folded into the base -> an HF directory the engine (and HF) loads
+    merged_dir = tmp_path / "merged"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train", "src", "merge_lora_weights.py"), "--model-path", str(out_dir), "--model-base", str(model_dir),
+                        "--save-model-path", str(merged_dir), "--safe-serialization"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    base_sd, merged_sd = load_file(str(model_dir / "model.safetensors")), load_file(str(merged_dir / "model.safetensors"))
+    k = "model.layers.1.mlp.down_proj.weight"
+    want = base_sd[k].float() + 2.0 * ad["base_model.model.model.layers.1.mlp.down_proj.lora_B.weight"].float() @ ad["base_model.model.model.layers.1.mlp.down_proj.lora_A.weight"].float()
+    assert torch.equal(merged_sd[k], want.to(torch.bfloat16)) and not torch.equal(merged_sd[k], base_sd[k])
+    assert torch.equal(merged_sd["visual.merger.mlp.2.weight"], base_sd["visual.merger.mlp.2.weight"]) and (merged_dir / "generation_config.json").exists()
+    VideoR2Model.from_pretrained(str(merged_dir))
+    # full fine-tune of the LM + the merger (no adapters), checkpoints every step, then a resumed launch
+    env2 = dict(env, OUTPUT_DIR=str(tmp_path / "out_full"))
+    full = small + ["--lora_enable", "False", "--freeze_llm", "False", "--freeze_merger", "False", "--save_strategy", "steps", "--save_steps", "1",
+                    "--merger_lr", "5e-4"]
+    steps2, err2 = launch(env2, *full, "--max_steps", "2")
+    assert [s["step"] for s in steps2] == [1, 2], err2[-3000:]
+    got = load_file(str(tmp_path / "out_full" / "model.safetensors"))
+    assert not torch.equal(got["model.layers.0.self_attn.o_proj.weight"], base_sd["model.layers.0.self_attn.o_proj.weight"])
+    assert not torch.equal(got["visual.merger.mlp.2.weight"], base_sd["visual.merger.mlp.2.weight"])
+    assert torch.equal(got["visual.blocks.0.attn.qkv.weight"], base_sd["visual.blocks.0.attn.qkv.weight"])            # the tower stayed frozen
+    steps3, err3 = launch(env2, *full, "--max_steps", "3")
+    assert "resumed from" in err3 and [s["step"] for s in steps3] == [3]

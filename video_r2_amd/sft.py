@@ -162,7 +162,8 @@ class QwenSFTTrainer:
             keep.append(lambda k: k.startswith("visual.") and not k.startswith("visual.merger."))
         if self.train_merger:
             keep.append(lambda k: k.startswith("visual.merger."))
-        return {k: v.cpu() for k, v in sd.items() if any(f(k) for f in keep)}
+        # named as peft's wrapper names them (base_model.model.<HF name>): the reference's loader strips that prefix (utils.py:68-71)
+        return {"base_model.model." + k: v.cpu() for k, v in sd.items() if any(f(k) for f in keep)}
 
     # ------------------------------------------------------------------ checkpoints: the GRPO trainer's (same optimiser state layout)
     def save_checkpoint(self, out_dir):

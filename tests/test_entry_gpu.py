@@ -224,3 +224,54 @@ def test_train_sft_sh_lora_recipe_then_merge_then_full_fine_tune(tmp_path):
     assert torch.equal(got["visual.blocks.0.attn.qkv.weight"], base_sd["visual.blocks.0.attn.qkv.weight"])            # the tower stayed frozen
     steps3, err3 = launch(env2, *full, "--max_steps", "3")
     assert "resumed from" in err3 and [s["step"] for s in steps3] == [3]
+
+
+def test_train_grpo_sh_with_lora_adapters(tmp_path):
+    """the GRPO entry with --lora_enable True (train_grpo.py:137-149,193-204 of the reference): the policy is base + adapters, the KL
+    reference the adapter-disabled model (kl == 0 at step 1 where B = 0, > 0 after the first update), rollouts come from the merged copy,
+    the output is the adapters in peft's layout and the base weights are written back untouched"""
+    import torch
+    from safetensors.torch import load_file
+    from video_r2_amd.model import VideoR2Model
+    ocfg = om.cfg_tiny(2)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), om.make_weights(ocfg, seed=44), device="cuda:0")
+    model_dir = tmp_path / "sft_model"
+    m.save_pretrained(str(model_dir))
+    base_sd = {k: v.clone() for k, v in m.state_dict().items()}
+    del m
+    clips = tmp_path / "videos"
+    (clips / "set").mkdir(parents=True)
+    rng = np.random.default_rng(2)
+    rows = []
+    for i in range(4):
+        np.savez(clips / "set" / f"c{i}.npz", frames=rng.integers(0, 256, size=(60, 56, 84, 3), dtype=np.uint8), fps=np.float32(30.0))
+        rows.append({"video": f"set/c{i}.npz", "key_frame": "",
+                     "conversations": [{"from": "human", "value": f"<video>\nQuestion {i}?\nA. yes\nB. no"}, {"from": "gpt", "value": "<answer>B</answer>"}],
+                     "temporal_grounding": {}})
+    data = tmp_path / "grpo.json"
+    data.write_text(json.dumps(rows))
+    (tmp_path / "my_reward_funcs.py").write_text(
+        "def text_length_reward(completions, **kwargs):\n"
+        "    return [float(i % 2) + 0.1 * (len(c[0]['content']) % 3) for i, c in enumerate(completions)]\n")
+    out_dir = tmp_path / "out"
+    env = dict(os.environ, PYTHONPATH=f"{tmp_path}:{os.environ.get('PYTHONPATH', '')}", NUM_DEVICES="1", MODEL_NAME=str(model_dir), DATA_PATH=str(data),
+               DATA_FOLDER=str(clips), SUBTITLES_FOLDER=str(tmp_path / "subs"), OUTPUT_DIR=str(out_dir), FPS_MAX_FRAMES="4", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    flags = ["--num_generations", "4", "--per_device_train_batch_size", "4", "--max_completion_length", "10", "--reward_module", "my_reward_funcs",
+             "--reward_func_names", "text_length_reward", "--reward_weights", "1.0", "--logging_steps", "1", "--save_steps", "2", "--learning_rate", "2e-3",
+             "--video_min_pixels", "4704", "--video_max_pixels", "4704", "--freeze_llm", "True", "--lora_enable", "True", "--lora_rank", "8", "--lora_alpha", "16",
+             "--lora_dropout", "0.05", "--lora_namespan_exclude", "['lm_head', 'embed_tokens']"]
+    steps, err = _launch(env, *flags, "--max_steps", "3")
+    assert [s["step"] for s in steps] == [1, 2, 3], err[-3000:]
+    assert steps[0]["kl"] == 0.0 and steps[2]["kl"] > 0.0 and all(np.isfinite(s["loss"]) and s["grad_norm"] > 0 for s in steps)
+    assert "LoRA: 14 adapted modules" in err
+    ad = load_file(str(out_dir / "adapter_model.safetensors"))
+    assert len(ad) == 28 and float(ad["base_model.model.model.layers.0.self_attn.v_proj.lora_B.weight"].abs().max()) > 0
+    non = torch.load(str(out_dir / "non_lora_state_dict.bin"), weights_only=True)
+    assert all(torch.equal(non["base_model.model." + k], v.cpu()) for k, v in base_sd.items())          # the base model did not move
+    ck = out_dir / "checkpoint-2"
+    assert (ck / "adapter_model.safetensors").exists() and (ck / "lora_state.pt").exists() and not (ck / "model.safetensors").exists()
+    steps2, err2 = _launch(env, *flags, "--max_steps", "4")                                            # resumes from the adapters of step 2
+    assert "resumed from" in err2 and [s["step"] for s in steps2] == [3, 4]
+    assert steps2[0]["loss"] == pytest.approx(steps[2]["loss"], rel=1e-4, abs=1e-6) and steps2[0]["kl"] == pytest.approx(steps[2]["kl"], rel=1e-3)

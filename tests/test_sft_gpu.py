@@ -189,7 +189,8 @@ def test_lora_sft_loss_and_adapter_gradients_vs_autograd(p):
             for site in SITES:
                 K = lo_e.W.shape[f"l{l}.{site}.A"][1]
                 ones, out = torch.ones(T, K, device="cuda:0", dtype=torch.bfloat16), torch.empty(T, K, device="cuda:0", dtype=torch.bfloat16)
-                lib.call("vr2_dropout_bf16", ones, K, out, K, T, K, p, lo_e.seed & 0xFFFFFFFF, lo_e._salt(fid, l, site), s)
+                sd_, salt = lo_e.draw_keys(fid, l, site)
+                lib.call("vr2_dropout_bf16", ones, K, out, K, T, K, p, sd_, salt, s)
                 for mod in site_mods[site]:
                     fin = lo_o.A[f"model.layers.{l}.{mod}"].shape[1]
                     mk[f"model.layers.{l}.{mod}"] = (out != 0).float().cpu()[None, :, :fin]

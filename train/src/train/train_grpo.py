@@ -165,6 +165,13 @@ def train(argv=None, processing_fn=None, dataset=None):
         log("trainable besides the LM: " + ", ".join(n for n, on in (("vision tower", tower), ("merger", merger)) if on)
             + " (the KL reference keeps a frozen copy of the vision side)")
     model = VideoR2Model.from_pretrained(args.model_id, device=device)
+    lora = None
+    if args.lora_enable:                       # train_grpo.py:137-149 of the reference: peft_config -> QwenGRPOTrainer(peft_config=...)
+        from video_r2_amd.lora import LoraTrainer
+        lora = LoraTrainer(model.engine, model.text, rank=args.lora_rank, alpha=args.lora_alpha, dropout=args.lora_dropout,
+                           num_modules=args.num_lora_modules, seed=args.seed)
+        log(f"LoRA: {len(lora.module_names())} adapted modules (rank {args.lora_rank}, alpha {args.lora_alpha}, dropout {args.lora_dropout}); the KL "
+            f"reference is the adapter-disabled model")
     if dataset is None:
         if not args.data_path:
             raise ValueError("--data_path is required")
@@ -179,7 +186,7 @@ def train(argv=None, processing_fn=None, dataset=None):
     sentence_model = rewards.load_sentence_model(names, args.sentence_model_name)
     reward_judge = rewards.load_reward_judge(names, args.reward_llm_judge)
     trainer = QwenGRPOTrainer(model, funcs, args, dataset, processing_fn, reward_weights=weights, reward_func_names=names,
-                              sentence_model=sentence_model, reward_judge=reward_judge)
+                              sentence_model=sentence_model, reward_judge=reward_judge, lora=lora)
     resume = args.resume_from_checkpoint or (checkpoints(args.output_dir)[-1][1] if checkpoints(args.output_dir) else "")
     if resume:
         trainer.load_checkpoint(resume)
@@ -212,7 +219,13 @@ def train(argv=None, processing_fn=None, dataset=None):
                 import torch.distributed as dist
                 dist.barrier()
     if rank == 0:
-        model.save_pretrained(args.output_dir)
+        if lora is not None:                   # train_grpo.py:193-204: the adapters in peft's layout + every non-adapter tensor
+            model.save_config(args.output_dir)
+            lora.save_adapter(args.output_dir, base_model_name_or_path=str(args.model_id))
+            torch.save({"base_model.model." + k: v.cpu() for k, v in model.state_dict().items()},
+                       os.path.join(args.output_dir, "non_lora_state_dict.bin"))
+        else:
+            model.save_pretrained(args.output_dir)
         copy_processor_files(args.model_id, args.output_dir)
         sink.save_state(args.output_dir, trainer)          # trainer.save_state() of the reference (train_grpo.py:189)
         sink.close()

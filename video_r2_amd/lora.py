@@ -98,7 +98,6 @@ class LoraTrainer:
         self.buckets = [("lora", 0, total)]
         self._finished = False
         self._fwd_id = 0
-        self._bwd_id = 0
         for l in range(self.L):                          # gate/up: the projection with the adapter's K columns appended
             nt_k = text.shape[f"l{l}.gu_w"]
             base = text[f"l{l}.gu_w"]
@@ -154,24 +153,33 @@ class LoraTrainer:
         self.W.shape[name] = tuple(w.shape)
 
     # ------------------------------------------------------------------ forward / backward pieces (called by train.Trainer)
+    def set_step(self, step):
+        """forward ids restart from the optimiser step, so a resumed run redraws the masks the original run drew at that step"""
+        self._fwd_id = int(step) << 20
+
     def begin_forward(self):
         self._fwd_id += 1
         return self._fwd_id
 
-    def _salt(self, fid, l, site):
-        return (fid * 4096 + l * 8 + SITES.index(site)) & 0xFFFFFFFF
+    def draw_keys(self, fid, l, site):
+        """(seed, salt) of one site's dropout draw: the 32-bit seed mixes the run's seed with the forward's id, the salt names the site"""
+        x = (self.seed * 0x9E3779B1 + (fid & 0xFFFFFFFF) * 0x85EBCA77 + (fid >> 32) * 0xC2B2AE3D + 0x27D4EB2F) & 0xFFFFFFFF
+        x ^= x >> 15
+        x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+        x ^= x >> 12
+        return x, l * 8 + SITES.index(site)
 
-    def _dropped(self, x, T, K, salt, tag):
+    def _dropped(self, x, T, K, keys, tag):
         if self.p == 0.0:
             return x
         xd = self.eng.buf("lora.xd." + tag, (T, K), torch.bfloat16)
-        lib.call("vr2_dropout_bf16", x, x.stride(0), xd, xd.stride(0), T, K, self.p, self.seed & 0xFFFFFFFF, salt, self.eng.s)
+        lib.call("vr2_dropout_bf16", x, x.stride(0), xd, xd.stride(0), T, K, self.p, keys[0], keys[1], self.eng.s)
         return xd
 
     def project(self, fid, l, site, x, t_out, T):
         """t_out[T, r'] (bf16, may be a strided view) = dropout(x) A^T"""
         kin = self.W.shape[f"l{l}.{site}.A"][1]
-        xd = self._dropped(x, T, kin, self._salt(fid, l, site), "f")
+        xd = self._dropped(x, T, kin, self.draw_keys(fid, l, site), "f")
         self.eng._gemm(xd, self.W, f"l{l}.{site}.A", None, t_out, T, EPI_BF16)
 
     def join(self, l, site, t, out_f32, T):
@@ -189,13 +197,27 @@ class LoraTrainer:
         eng._gemm(dY, self.W, f"l{l}.{site}.Bt", None, dt, T, EPI_BF16)
         gB, gA = self.grad[(l, site, "B")], self.grad[(l, site, "A")]
         lib.call("vr2_gemm_tn_bf16", dY, dY.stride(0), t, t.stride(0), gB, gB.stride(0), n_out, rr, T, 1, eng.s)
-        salt = self._salt(fid, l, site)
-        xd = self._dropped(x, T, kin, salt, "b")
+        keys = self.draw_keys(fid, l, site)
+        xd = self._dropped(x, T, kin, keys, "b")
         lib.call("vr2_gemm_tn_bf16", dt, dt.stride(0), xd, xd.stride(0), gA, gA.stride(0), rr, kin, T, 1, eng.s)
         g32 = eng.buf("lora.g32", (T, kin), torch.float32)
         eng._gemm(dt, self.W, f"l{l}.{site}.At", None, g32, T, EPI_F32)
         lib.call("vr2_dropout_add", g32, g32.stride(0), dst, dst.stride(0), 1 if dst.dtype == torch.bfloat16 else 0, T, kin, self.p,
-                 self.seed & 0xFFFFFFFF, salt, eng.s)
+                 keys[0], keys[1], eng.s)
+
+    def merge_into(self, dst: Params, base: Params):
+        """dst's projections <- base W + s B A (fp32 sum, one rounding, re-packed): the adapted model as plain weights, for the passes
+        that take no gradient (rollout prefill / decode, old-policy scoring) -- peft's merge(), without touching the base copies the
+        training forward and the adapter-disabled KL reference read"""
+        from .weights import unpack_tiles
+        with torch.cuda.stream(self.eng.stream):
+            for l in range(self.L):
+                for site in SITES:
+                    name = f"l{l}.{self.base[site]}"
+                    n, kp = base.shape[name]
+                    w = unpack_tiles(base[name], n, kp).float()
+                    w.addmm_(self.master[(l, site, "B")], self.master[(l, site, "A")], alpha=self.scaling)
+                    dst.t[name].copy_(pack_tiles(w.to(torch.bfloat16)))
 
     def finish_grads(self):
         """once per optimiser step, before the exchange / the norm: the B gradients take their factor s, and everything outside the

@@ -120,6 +120,8 @@ class QwenSFTTrainer:
         a, eng = self.args, self.model.engine
         if processed is None:
             processed = [[self.processing_fn(ex) for ex in mb] for mb in microbatches]
+        if self.lora is not None:
+            self.lora.set_step(self.global_step * self.world + self.rank)       # dropout draws: a function of (seed, step, rank, row)
         mb_losses = []
         for k, mb in enumerate(processed):
             toks = [int(split_supervised(p["input_ids"], p["labels"])[2].sum()) for p in mb]
@@ -168,14 +170,9 @@ class QwenSFTTrainer:
     # ------------------------------------------------------------------ checkpoints: the GRPO trainer's (same optimiser state layout)
     def save_checkpoint(self, out_dir):
         from .trainer import QwenGRPOTrainer
-        d = QwenGRPOTrainer.save_checkpoint(self, out_dir)
-        if self.lora is not None:
-            self.lora.save_training_state(d)
-        return d
+        return QwenGRPOTrainer.save_checkpoint(self, out_dir)
 
     def load_checkpoint(self, ckpt_dir):
         from .trainer import QwenGRPOTrainer
         QwenGRPOTrainer.load_checkpoint(self, ckpt_dir)
-        if self.lora is not None:
-            self.lora.load_training_state(ckpt_dir)
         return self

@@ -75,7 +75,7 @@ def call_reward_funcs(reward_funcs, reward_func_names, examples, texts_per_examp
 
 class QwenGRPOTrainer:
     def __init__(self, model: VideoR2Model, reward_funcs, args, train_dataset, processing_fn, reward_weights=None,
-                 reward_func_names=None, ref_params=None, sentence_model=None, reward_judge=(None, None)):
+                 reward_func_names=None, ref_params=None, sentence_model=None, reward_judge=(None, None), lora=None):
         """processing_fn(example) -> dict(input_ids 1-D int array (unpadded prompt), second_per_grid_ts,
         decode(completion_ids) -> list[str], and the clip(s) as ONE of: videos = [(uint8 frames [n,3,H,W], (H', W'))] (resize
         + normalise + patchify on the device: host/frontend.py ProcessingFrontEnd), video_frames_u8 (already resized),
@@ -91,7 +91,20 @@ class QwenGRPOTrainer:
         self.processing_fn = processing_fn
         self.num_generations = args.num_generations
         self.beta = args.beta
-        self.ref_params = ref_params if (ref_params is not None or args.beta == 0.0) else model.reference_copy()
+        # LoRA (--lora_enable True, peft_config of grpo_trainer.py:256-269,315-318): the policy is base + adapters; the KL reference is the
+        # SAME model with the adapters disabled (:340-343,830-833) = the frozen base weights, no second copy.  The passes that take no
+        # gradient (rollouts, old-policy scoring) run on a merged copy W + s B A, refreshed after every optimiser step
+        self.lora = lora
+        if lora is not None:
+            if getattr(args, "decode_weights", "bf16") != "bf16" or getattr(args, "sync_ref_model", False):
+                raise NotImplementedError("--lora_enable True with --decode_weights fp8 / --sync_ref_model: not built (the reference model is "
+                                          "the adapter-disabled policy; the merged rollout copy is bf16)")
+            self.ref_params = None if args.beta == 0.0 else model.text
+            self.policy = vw.clone_params(model.text)
+            lora.merge_into(self.policy, model.text)
+        else:
+            self.ref_params = ref_params if (ref_params is not None or args.beta == 0.0) else model.reference_copy()
+            self.policy = model.text
         self.epsilon_low = args.epsilon
         self.epsilon_high = args.epsilon_high if args.epsilon_high is not None else args.epsilon
         self._metrics = {"train": defaultdict(list), "eval": defaultdict(list)}
@@ -165,7 +178,7 @@ class QwenGRPOTrainer:
         # from arguments that do not mention them at all (tests, embedding callers) keeps the frozen default of the shipped recipe
         self.train_tower = getattr(args, "train_vision_tower", False)
         self.train_merger = getattr(args, "train_merger", False)
-        self.update = train_lm or self.train_tower or self.train_merger       # anything to train at all
+        self.update = train_lm or self.train_tower or self.train_merger or lora is not None      # anything to train at all
         self.ref_vision = None
         vis_tr = None
         if self.train_tower or self.train_merger:
@@ -176,7 +189,7 @@ class QwenGRPOTrainer:
         # --freeze_llm True under a trainable vision side (configure_llm, train_grpo.py:59-64): the LM's backward still runs -- the
         # vision gradient arrives through it -- but computes input gradients only
         self.updater = (UpdateEngine(model.engine, model.text, grad_exchange=getattr(args, "grad_exchange_dtype", "fp32"), vision_trainer=vis_tr,
-                                     train_lm=train_lm) if self.update else None)
+                                     train_lm=train_lm, lora=lora) if self.update else None)
         self.steps_per_epoch = len(train_dataset) // self.groups_per_step
         n_steps = int(self.steps_per_epoch * float(args.num_train_epochs)) * max(1, args.num_iterations)
         self.total_steps = args.max_steps if args.max_steps > 0 else max(1, n_steps)
@@ -233,8 +246,8 @@ class QwenGRPOTrainer:
             with self.prof.phase("generate"):          # vision tower + prompt prefill + decode (model.generate, :783-786)
                 enc = eng.encode_videos([c for cl in clips for c in cl], per_prompt=[len(cl) for cl in clips])
                 encs = [(emb, plan, pi.get("second_per_grid_ts")) for (emb, plan), pi in zip(enc, pis)]
-                states = eng.prefill_batch(m.text, [(ids, emb, plan, sec) for ids, (emb, plan, sec) in zip(idss, encs)], slots, tag="pol")
-                toks_all, _ = eng.decode(m.text, states if len(states) > 1 else states[0], G, a.max_completion_length,
+                states = eng.prefill_batch(self.policy, [(ids, emb, plan, sec) for ids, (emb, plan, sec) in zip(idss, encs)], slots, tag="pol")
+                toks_all, _ = eng.decode(self.policy, states if len(states) > 1 else states[0], G, a.max_completion_length,
                                          temperature=a.temperature, top_k=a.top_k, seed=seed + 7919 * c0,
                                          eos_token_id=m.cfg.eos_token_id, **self.sampling)
             new = []
@@ -269,7 +282,7 @@ class QwenGRPOTrainer:
                                                             ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"]).clone()
                         # (clone: the scoring output is a workspace that the next pass over it reuses)
                     if not self.update:
-                        ro["logps"] = eng.score_unified(m.text, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"],
+                        ro["logps"] = eng.score_unified(self.policy, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"], ro["completion_ids"],
                                                         a.temperature, tag="ref", lens=ro["lens"], allow_fp8=False).clone()
                     ro.pop("_state")
         rewards = pending.result() if pending is not None else self._rewards(examples, groups)
@@ -321,7 +334,7 @@ class QwenGRPOTrainer:
             if a.num_iterations > 1:
                 for ro in rollouts:      # old-policy log-probs, fixed for the iterations that re-use this rollout: the training
                     # forward's own arithmetic (unified row space, bf16 GEMMs also under config 5) -> ratio == 1 at iteration 0
-                    ro["old_logps"] = self.model.engine.score_unified(self.model.text, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"],
+                    ro["old_logps"] = self.model.engine.score_unified(self.policy, ro["prompt_ids"], ro["emb"], ro["plan"], ro["sec"],
                                                                       ro["completion_ids"], a.temperature, tag="ref", lens=ro["lens"],
                                                                       allow_fp8=False).clone()
             self._buffered = (rollouts, adv)
@@ -333,6 +346,8 @@ class QwenGRPOTrainer:
         G = self.local_generations               # rows this rank holds per prompt group
         # a reference micro-batch that spans several groups (per_device_train_batch_size > G) normalises the token-mean losses
         # by ITS token count: group g's share is tokens_g / tokens_block, applied as a scale on that group's loss and gradient
+        if getattr(self, "lora", None) is not None:
+            self.lora.set_step(self.global_step * vdist.world_size() + vdist.rank())   # dropout draws: a function of (seed, step, rank, group)
         scale = [1.0] * len(rollouts)
         if self.block_groups > 1 and a.loss_type in ("bnpo", "mapo_bnpo"):
             ntok = [float(ro["completion_mask"].sum().item()) for ro in rollouts]
@@ -401,6 +416,8 @@ class QwenGRPOTrainer:
             with self.prof.phase("optimizer_step"):
                 gn = self.updater.optimizer_step(lr=lr, weight_decay=a.weight_decay, beta1=a.adam_beta1, beta2=a.adam_beta2,
                                                  eps=a.adam_epsilon, max_grad_norm=a.max_grad_norm, grad_scale=1.0 / len(rollouts))
+            if self.lora is not None:                              # the next rollout samples from the updated adapters
+                self.lora.merge_into(self.policy, self.model.text)
             local["grad_norm"] = gn.item()
             eng.sync()
             local["learning_rate"] = lr
@@ -514,7 +531,12 @@ class QwenGRPOTrainer:
         """HF-layout weights (loadable by eval/lmms-eval and demo/ unchanged) + optimiser / trainer state for resume."""
         import os
         d = os.path.join(out_dir, f"checkpoint-{self.global_step}")
-        self.model.save_pretrained(d)
+        if getattr(self, "lora", None) is not None:     # a peft model's checkpoint: the adapters (+ their optimiser state below), not the base
+            self.model.save_config(d)
+            self.lora.save_adapter(d, base_model_name_or_path=str(getattr(self.args, "model_id", "")))
+            self.lora.save_training_state(d)
+        else:
+            self.model.save_pretrained(d)
         state = {"global_step": self.global_step, "num_input_tokens_seen": self.num_input_tokens_seen}
         if self.updater is not None:
             st = self.updater.state
@@ -546,6 +568,10 @@ class QwenGRPOTrainer:
                 for k in vs.master:
                     vs.master[k].copy_(state["vision"]["master"][k]); vs.m[k].copy_(state["vision"]["m"][k]); vs.v[k].copy_(state["vision"]["v"][k])
             self.updater.refresh_compute_copies()
+        if getattr(self, "lora", None) is not None and os.path.exists(os.path.join(ckpt_dir, "lora_state.pt")):
+            self.lora.load_training_state(ckpt_dir)
+            if getattr(self, "policy", None) is not None and self.policy is not self.model.text:
+                self.lora.merge_into(self.policy, self.model.text)
         if "ref" in state and self.ref_params is not None:
             for k, v in state["ref"].items():
                 if k in self.ref_params.t:

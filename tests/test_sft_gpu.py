@@ -278,3 +278,57 @@ def test_lora_with_zero_b_is_the_base_model_bit_for_bit_and_merge_matches_the_ad
     m2.engine.sync()
     d = rel_err(lp_ad.cpu().numpy(), lp_m.cpu().numpy())
     assert d.max() < 2e-2 and np.median(d) < 3e-3 and not torch.equal(lp_ad, lp_base)
+
+
+def _sft_dp_worker(rank, world, port, q, mode):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      VR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from video_r2_amd import dist as vdist
+    from video_r2_amd.lora import LoraTrainer
+    from video_r2_amd.model import VideoR2Model
+    from video_r2_amd.sft import QwenSFTTrainer
+    torch.cuda.set_device(0)
+    vdist.init(device="cuda:0")
+    ocfg = om.cfg_tiny(2)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), om.make_weights(ocfg, seed=31), device="cuda:0")
+    lora_flags = ["--freeze_llm", "True", "--lora_enable", "True", "--lora_rank", "8", "--lora_alpha", "16", "--lora_namespan_exclude", "['lm_head', 'embed_tokens']"]
+    args = params.parse_sft_args(["--freeze_vision_tower", "True", "--freeze_merger", "True", "--learning_rate", "1e-3", "--warmup_steps", "0",
+                                  "--gradient_accumulation_steps", "2", "--max_steps", "2", "--grad_exchange_dtype", "bf16" if mode == "lora" else "fp32"]
+                                 + (lora_flags if mode == "lora" else []))
+    lora = LoraTrainer(m.engine, m.text, rank=8, alpha=16, dropout=0.05, seed=args.seed) if mode == "lora" else None
+    pool = _rows(m.cfg, 31, n_text=7)                        # 8 rows: rank r takes batches r, r + 2, ... of the permutation
+    tr = QwenSFTTrainer(m, args, pool, lambda ex: ex, lora=lora)
+    steps = list(tr.iter_steps())
+    out = tr.step(steps[0])
+    out = tr.step(steps[1])
+    torch.cuda.synchronize()
+    assert tr.updater._works == {}
+    sig = (float(lora.master[(1, "gu", "B")].double().sum()) + float(lora.master[(0, "qkv", "A")].double().sum())) if lora is not None \
+        else float(m.text["l0.o_w"].float().sum()) + float(m.text["l1.ln2"].sum())
+    q.put((rank, [len(mb[0]["input_ids"]) for mb in steps[0]], out["metrics"]["loss"], out["metrics"]["grad_norm"], sig))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["full", "lora"])
+def test_two_rank_sft_steps_keep_replicas_identical(mode):
+    """world_size 2 on the one GPU (gloo): the ranks take different rows (batch k of the epoch's permutation goes to rank k mod 2),
+    average their gradients -- the LM's buckets, or the adapters' single bucket on the bf16 wire -- and end two optimiser steps with
+    bit-identical weights / adapters and the same reduced metrics"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sft_dp_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, rows0, l0, g0, s0), (r1, rows1, l1, g1, s1) = res
+    assert len(rows0) == len(rows1) == 2                       # two accumulated micro-batches per rank and step
+    assert l0 == l1 and g0 == g1 and g0 > 0 and s0 == s1

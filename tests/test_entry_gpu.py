@@ -211,7 +211,10 @@ def test_train_sft_sh_lora_recipe_then_merge_then_full_fine_tune(tmp_path):
     want = base_sd[k].float() + 2.0 * ad["base_model.model.model.layers.1.mlp.down_proj.lora_B.weight"].float() @ ad["base_model.model.model.layers.1.mlp.down_proj.lora_A.weight"].float()
     assert torch.equal(merged_sd[k], want.to(torch.bfloat16)) and not torch.equal(merged_sd[k], base_sd[k])
     assert torch.equal(merged_sd["visual.merger.mlp.2.weight"], base_sd["visual.merger.mlp.2.weight"]) and (merged_dir / "generation_config.json").exists()
-    VideoR2Model.from_pretrained(str(merged_dir))
+    m_merged = VideoR2Model.from_pretrained(str(merged_dir))
+    m_direct = VideoR2Model.from_pretrained(str(out_dir))             # the adapter directory itself: merged on load over base_model_name_or_path
+    assert torch.equal(m_direct.text["l1.down_w"], m_merged.text["l1.down_w"]) and torch.equal(m_direct.text["l0.qkv_w"], m_merged.text["l0.qkv_w"])
+    del m_merged, m_direct
     # full fine-tune of the LM + the merger (no adapters), checkpoints every step, then a resumed launch
     env2 = dict(env, OUTPUT_DIR=str(tmp_path / "out_full"))
     full = small + ["--lora_enable", "False", "--freeze_llm", "False", "--freeze_merger", "False", "--save_strategy", "steps", "--save_steps", "1",

@@ -115,3 +115,36 @@ def test_sft_loss_is_the_shifted_token_mean():
     lp = torch.log_softmax(logits, -1)
     want = -(lp[0, 1, 3] + lp[0, 2, 4] + lp[1, 0, 1] + lp[1, 3, 6]) / 4            # position t predicts token t + 1
     assert abs(float(osft.sft_loss(logits, labels)) - float(want)) < 1e-6
+
+
+def test_adapter_directory_loads_as_the_merged_model(tmp_path):
+    """weights.load_state_dict on a directory of LoRA adapters = the reference's load_pretrained_model(model_path, model_base)
+    (/root/reference/train/src/utils.py:48-76): base weights, non_lora_state_dict.bin over them, W + alpha / r * B A on the adapted
+    layers; oracle.sft.LoraOracle.merged is the same sum"""
+    import torch
+    from safetensors.torch import save_file
+    from video_r2_amd import weights as W
+    ocfg = om.cfg_tiny(2)
+    w = om.make_weights(ocfg, seed=5)
+    base, ad = tmp_path / "base", tmp_path / "adapters"
+    base.mkdir(); ad.mkdir()
+    save_file({k: v.to(torch.bfloat16).contiguous() for k, v in w.items()}, str(base / "model.safetensors"))
+    lo = osft.LoraOracle(w, ocfg.text.num_hidden_layers, 8, 16, seed=1, b_std=0.02)
+    sd = {}
+    for k in lo.A:
+        sd[f"base_model.model.{k}.lora_A.weight"] = lo.A[k].detach().contiguous()
+        sd[f"base_model.model.{k}.lora_B.weight"] = lo.B[k].detach().contiguous()
+    save_file(sd, str(ad / "adapter_model.safetensors"))
+    (ad / "adapter_config.json").write_text(json.dumps({"peft_type": "LORA", "r": 8, "lora_alpha": 16, "bias": "none", "base_model_name_or_path": str(base)}))
+    new_ln = torch.full_like(w["visual.merger.ln_q.weight"], 0.5)
+    torch.save({"base_model.model.visual.merger.ln_q.weight": new_ln}, str(ad / "non_lora_state_dict.bin"))
+    got = W.load_state_dict(str(ad))
+    want = lo.merged(w)
+    for k in ("model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.up_proj.weight", "model.layers.1.mlp.down_proj.weight"):
+        assert torch.equal(got[k], want[k].to(torch.bfloat16)) and not torch.equal(got[k], w[k].to(torch.bfloat16))
+    assert torch.equal(got["visual.merger.ln_q.weight"].float(), new_ln) and torch.equal(got["lm_head.weight"].float(), w["lm_head.weight"])
+    assert set(got) == set(w)
+    (ad / "adapter_config.json").write_text(json.dumps({"peft_type": "LORA", "r": 8, "lora_alpha": 16, "base_model_name_or_path": "/nonexistent"}))
+    with pytest.raises(FileNotFoundError, match="base model"):
+        W.load_state_dict(str(ad))
+    assert set(W.load_state_dict(str(ad), model_base=str(base))) == set(w)

@@ -21,22 +21,13 @@ for p_ in (ROOT, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train
 
 def merge_lora(args):
     import torch
-    from safetensors.torch import load_file, save_file
+    from safetensors.torch import save_file
     from video_r2_amd import weights as W
-    from video_r2_amd.lora import merged_state_dict
     from train_grpo import copy_processor_files
     cfg = json.load(open(os.path.join(args.model_path, "adapter_config.json")))
     if cfg.get("peft_type") != "LORA" or cfg.get("use_dora") or cfg.get("bias", "none") != "none":
         raise NotImplementedError(f"adapter_config.json: {cfg.get('peft_type')} / use_dora={cfg.get('use_dora')} / bias={cfg.get('bias')}: plain LoRA with bias none is what merges here")
-    base = W.load_state_dict(args.model_base)
-    extra = os.path.join(args.model_path, "non_lora_state_dict.bin")
-    if os.path.exists(extra):
-        for k, v in torch.load(extra, map_location="cpu", weights_only=True).items():
-            k = k[len("base_model."):] if k.startswith("base_model.") else k          # utils.py:68-71: peft's wrapper prefixes
-            k = k[len("model."):] if k.startswith(("model.model.", "model.visual.", "model.lm_head.")) else k
-            if k in base:
-                base[k] = v.to(base[k].dtype)
-    merged = merged_state_dict(base, load_file(os.path.join(args.model_path, "adapter_model.safetensors")), cfg["lora_alpha"] / cfg["r"])
+    merged = W.load_state_dict(args.model_path, model_base=args.model_base)     # base + non-LoRA trainables + W + alpha / r * B A
     os.makedirs(args.save_model_path, exist_ok=True)
     src_cfg = os.path.join(args.model_path if os.path.exists(os.path.join(args.model_path, "config.json")) else args.model_base, "config.json")
     with open(src_cfg) as f, open(os.path.join(args.save_model_path, "config.json"), "w") as g:

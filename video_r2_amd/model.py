@@ -138,9 +138,11 @@ class VideoR2Model:
 
     # ------------------------------------------------------------------ loading / saving (HF layout)
     @classmethod
-    def from_pretrained(cls, path, device="cuda:0", **_ignored):
-        cfg = ModelConfig.from_pretrained(path)
-        sd = W.load_state_dict(path)
+    def from_pretrained(cls, path, device="cuda:0", model_base=None, **_ignored):
+        """an HF checkpoint directory, or a directory of LoRA adapters over `model_base` (merged on load, as the reference's
+        load_pretrained_model does)"""
+        cfg = ModelConfig.from_pretrained(path if os.path.exists(os.path.join(path, "config.json")) or model_base is None else model_base)
+        sd = W.load_state_dict(path, model_base=model_base)
         return cls(cfg, W.build_vision(cfg, sd, device), W.build_text(cfg, sd, device), device=device)
 
     @classmethod

@@ -76,9 +76,30 @@ def normalise_keys(sd):
     return out
 
 
-def load_state_dict(path):
-    """Read every *.safetensors shard of an HF checkpoint directory (safe loader, nothing executed)."""
+def load_state_dict(path, model_base=None):
+    """Read every *.safetensors shard of an HF checkpoint directory (safe loader, nothing executed).  A directory that holds LoRA
+    adapters (adapter_config.json + adapter_model.safetensors: what the SFT / GRPO stages write under --lora_enable) is loaded the way
+    the reference's `load_pretrained_model(model_path, model_base)` does (/root/reference/train/src/utils.py:48-76): the base model
+    (model_base, else the adapter config's base_model_name_or_path), the trainable non-adapter tensors of non_lora_state_dict.bin over
+    it, then W + alpha / r * B A merged into every adapted layer."""
     from safetensors.torch import load_file
+    if os.path.exists(os.path.join(path, "adapter_config.json")) and os.path.exists(os.path.join(path, "adapter_model.safetensors")):
+        with open(os.path.join(path, "adapter_config.json")) as f:
+            acfg = json.load(f)
+        base = model_base or acfg.get("base_model_name_or_path") or ""
+        if not os.path.isdir(base):
+            raise FileNotFoundError(f"{path} holds LoRA adapters; their base model directory {base!r} (model_base / base_model_name_or_path) "
+                                    f"is not there")
+        sd = load_state_dict(base)
+        extra = os.path.join(path, "non_lora_state_dict.bin")
+        if os.path.exists(extra):
+            for k, v in torch.load(extra, map_location="cpu", weights_only=True).items():
+                k = k[len("base_model."):] if k.startswith("base_model.") else k
+                k = k[len("model."):] if k.startswith(("model.model.", "model.visual.", "model.lm_head.")) else k
+                if k in sd:
+                    sd[k] = v.to(sd[k].dtype)
+        from .lora import merged_state_dict
+        return merged_state_dict(sd, load_file(os.path.join(path, "adapter_model.safetensors")), acfg["lora_alpha"] / acfg["r"])
     idx = os.path.join(path, "model.safetensors.index.json")
     if os.path.exists(idx):
         with open(idx) as f:

@@ -332,3 +332,22 @@ def test_two_rank_sft_steps_keep_replicas_identical(mode):
     (r0, rows0, l0, g0, s0), (r1, rows1, l1, g1, s1) = res
     assert len(rows0) == len(rows1) == 2                       # two accumulated micro-batches per rank and step
     assert l0 == l1 and g0 == g1 and g0 > 0 and s0 == s1
+
+
+def test_num_lora_modules_keeps_the_last_modules_in_module_order():
+    """--num_lora_modules 3 (find_target_linear_names, train_sft.py:24-39: `lora_module_names[-num_lora_modules:]`): the last decoder
+    layer's gate / up / down projections and nothing else"""
+    from video_r2_amd.lora import LoraTrainer
+    from video_r2_amd.model import VideoR2Model
+    ocfg = om.cfg_tiny(2)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), om.make_weights(ocfg, seed=12), device="cuda:0")
+    lo = LoraTrainer(m.engine, m.text, rank=8, alpha=16, dropout=0.0, num_modules=3, seed=1)
+    L, t = ocfg.text.num_hidden_layers, ocfg.text
+    assert lo.module_names() == [f"model.layers.{L - 1}.mlp.{n}_proj" for n in ("down", "gate", "up")]
+    assert osft.target_module_names(L, 3) == [f"model.layers.{L - 1}.mlp.{n}_proj" for n in ("gate", "up", "down")]
+    assert lo.n_params() == 8 * (2 * (t.hidden_size + t.intermediate_size) + (t.intermediate_size + t.hidden_size))
+    assert set(k.split(".lora_")[0] for k in lo.adapter_state_dict()) == {f"base_model.model.model.layers.{L - 1}.mlp.{n}_proj" for n in ("gate", "up", "down")}
+    for key, mk in lo.mask.items():
+        on = key[0] == L - 1 and key[1] in ("gu", "down")
+        assert (float(mk.sum()) > 0) == on, key
+        assert float(lo.master[key].abs().sum()) == 0.0 or on

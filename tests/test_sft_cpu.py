@@ -148,3 +148,27 @@ def test_adapter_directory_loads_as_the_merged_model(tmp_path):
     with pytest.raises(FileNotFoundError, match="base model"):
         W.load_state_dict(str(ad))
     assert set(W.load_state_dict(str(ad), model_base=str(base))) == set(w)
+
+
+def test_sft_row_order_shards_batches_over_ranks_and_resumes():
+    """iter_steps is host logic: per epoch a permutation of (seed + epoch), consecutive batches of per_device_train_batch_size rows,
+    batch k to rank k mod world, `accum` of a rank's batches per optimiser step; a resumed trainer skips the steps it has done"""
+    from types import SimpleNamespace
+    from video_r2_amd.sft import QwenSFTTrainer
+
+    def make(rank, world, done=0, n=22, bs=2, accum=2, steps=5):
+        t = QwenSFTTrainer.__new__(QwenSFTTrainer)
+        t.dataset, t.args = list(range(n)), SimpleNamespace(seed=42)
+        t.rank, t.world, t.bs, t.accum, t.total_steps, t.global_step = rank, world, bs, accum, steps, done
+        return t
+    r0, r1 = list(make(0, 2).iter_steps()), list(make(1, 2).iter_steps())
+    assert len(r0) == len(r1) == 5 and all(len(s) == 2 and all(len(mb) == 2 for mb in s) for s in r0 + r1)
+    # 22 rows / (2 x 2 x 2) = 2 whole steps per epoch (the 6 leftover rows of an epoch are dropped): steps 0-1 epoch 0, 2-3 epoch 1, 4 epoch 2
+    for e, (a, b) in enumerate([(0, 2), (2, 4)]):
+        seen = [i for s in r0[a:b] + r1[a:b] for mb in s for i in mb]
+        import torch
+        order = torch.randperm(22, generator=torch.Generator().manual_seed(42 + e)).tolist()
+        assert sorted(seen) == sorted(order[:16]) and len(set(seen)) == 16
+        assert r0[a][0] == order[0:2] and r1[a][0] == order[2:4] and r0[a][1] == order[4:6]        # batch k -> rank k mod 2
+    assert list(make(0, 2, done=3).iter_steps()) == r0[3:]
+    assert list(make(0, 1, n=3, bs=2, accum=2, steps=4).iter_steps()) == []                          # fewer rows than one step: nothing to do

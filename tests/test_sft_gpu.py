@@ -159,11 +159,36 @@ def _lora_pair(ocfg, m, w, r, alpha, p, b_std):
     return lo_o, lo_e
 
 
+def _dropout_masks(lo_e, lo_o, rows, p, n_layers, first_fid=1):
+    """per row: {HF module: 0/1 mask [1, T, in]} = the draws the engine's forward number first_fid + i will make (one per fused site,
+    shared by the site's modules), taken from the dropout kernel itself on a block of ones"""
+    from video_r2_amd import lib
+    from video_r2_amd.lora import SITES
+    site_mods = {"qkv": ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), "o": ("self_attn.o_proj",),
+                 "gu": ("mlp.gate_proj", "mlp.up_proj"), "down": ("mlp.down_proj",)}
+    s = torch.cuda.current_stream().cuda_stream
+    out_all = []
+    for fid, r in enumerate(rows, start=first_fid):
+        T = len(r["input_ids"])
+        mk = {}
+        for l in range(n_layers):
+            for site in SITES:
+                K = lo_e.W.shape[f"l{l}.{site}.A"][1]
+                ones, out = torch.ones(T, K, device="cuda:0", dtype=torch.bfloat16), torch.empty(T, K, device="cuda:0", dtype=torch.bfloat16)
+                sd_, salt = lo_e.draw_keys(fid, l, site)
+                lib.call("vr2_dropout_bf16", ones, K, out, K, T, K, p, sd_, salt, s)
+                for mod in site_mods[site]:
+                    fin = lo_o.A[f"model.layers.{l}.{mod}"].shape[1]
+                    mk[f"model.layers.{l}.{mod}"] = (out != 0).float().cpu()[None, :, :fin]
+        out_all.append(mk)
+    torch.cuda.synchronize()
+    return out_all
+
+
 @pytest.mark.parametrize("p", [0.0, 0.25])
 def test_lora_sft_loss_and_adapter_gradients_vs_autograd(p):
     """base + B A (dropout(x)) * alpha / r on every LM linear layer, B != 0, against autograd through the oracle with the engine's own
     dropout draws; the frozen LM holds no gradients; peft-layout round trip; one optimiser step changes only the adapters"""
-    from video_r2_amd import lib
     from video_r2_amd.lora import SITES
     from video_r2_amd.model import VideoR2Model
     from video_r2_amd.sft import QwenSFTTrainer
@@ -178,24 +203,7 @@ def test_lora_sft_loss_and_adapter_gradients_vs_autograd(p):
     tr = QwenSFTTrainer(m, args, list(range(4)), lambda ex: ex, lora=lo_e)
     rows = _rows(m.cfg, 77)
     n_mb = sum(int((r["labels"][1:] != -100).sum()) for r in rows)
-    masks_of = []                                          # per row: the masks its forward will draw (forward ids 1, 2 in order)
-    s = torch.cuda.current_stream().cuda_stream
-    site_mods = {"qkv": ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), "o": ("self_attn.o_proj",),
-                 "gu": ("mlp.gate_proj", "mlp.up_proj"), "down": ("mlp.down_proj",)}
-    for fid, r in enumerate(rows, start=1):
-        T = len(r["input_ids"])
-        mk = {}
-        for l in range(ocfg.text.num_hidden_layers):
-            for site in SITES:
-                K = lo_e.W.shape[f"l{l}.{site}.A"][1]
-                ones, out = torch.ones(T, K, device="cuda:0", dtype=torch.bfloat16), torch.empty(T, K, device="cuda:0", dtype=torch.bfloat16)
-                sd_, salt = lo_e.draw_keys(fid, l, site)
-                lib.call("vr2_dropout_bf16", ones, K, out, K, T, K, p, sd_, salt, s)
-                for mod in site_mods[site]:
-                    fin = lo_o.A[f"model.layers.{l}.{mod}"].shape[1]
-                    mk[f"model.layers.{l}.{mod}"] = (out != 0).float().cpu()[None, :, :fin]
-        masks_of.append(mk)
-    torch.cuda.synchronize()
+    masks_of = _dropout_masks(lo_e, lo_o, rows, p, ocfg.text.num_hidden_layers)
     parts = [tr._row(r, 1.0 / n_mb, last=(i == len(rows) - 1)) for i, r in enumerate(rows)]
     m.engine.sync()
     loss = sum(float(nll.item()) for nll, _ in parts) / n_mb

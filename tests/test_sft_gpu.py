@@ -359,3 +359,40 @@ def test_num_lora_modules_keeps_the_last_modules_in_module_order():
         on = key[0] == L - 1 and key[1] in ("gu", "down")
         assert (float(mk.sum()) > 0) == on, key
         assert float(lo.master[key].abs().sum()) == 0.0 or on
+
+
+def test_lora_beside_a_trainable_merger():
+    """--lora_enable True --freeze_merger False (train_sft.py:171-184 of the reference re-enables the merger's requires_grad after
+    get_peft_model): adapters on the frozen LM AND the merger's own tensors train in one step; both sets of gradients against autograd,
+    and non_lora_state_dict.bin carries the merger (and only the merger) under peft's names"""
+    from tests.test_vision_train_gpu import _vision_grads_as_hf
+    from video_r2_amd.lora import SITES
+    from video_r2_amd.model import VideoR2Model
+    from video_r2_amd.sft import QwenSFTTrainer
+    ocfg = om.cfg_tiny(2)
+    w = om.make_weights(ocfg, seed=91)
+    m = VideoR2Model.from_state_dict(to_engine_cfg(ocfg), w, device="cuda:0")
+    args = params.parse_sft_args(["--freeze_llm", "True", "--freeze_vision_tower", "True", "--freeze_merger", "False", "--lora_enable", "True", "--lora_rank", "8",
+                                  "--lora_alpha", "16", "--lora_dropout", "0.0", "--lora_namespan_exclude", "['lm_head', 'embed_tokens']", "--merger_lr", "1e-4"])
+    lo_o, lo_e = _lora_pair(ocfg, m, w, 8, 16, 0.0, 0.02)
+    tr = QwenSFTTrainer(m, args, list(range(4)), lambda ex: ex, lora=lo_e)
+    assert tr.updater.vis is not None and tr.updater.vis.train_merger and not tr.updater.vis.train_tower and not tr.updater.train_lm
+    rows = _rows(m.cfg, 91, n_text=0)
+    n_mb = int((rows[0]["labels"][1:] != -100).sum())
+    nll, _ = tr._row(rows[0], 1.0 / n_mb, last=True)
+    m.engine.sync()
+    o_loss, o_grads = _oracle_step(ocfg, w, rows, lambda k: k.startswith("visual.merger."), lora=lambda r: lo_o.hooks())
+    assert abs(float(nll.item()) / n_mb - o_loss) < 2e-3 * abs(o_loss)
+    got = _vision_grads_as_hf(tr.updater.vis.state, m.cfg)
+    assert set(got) == set(o_grads) and len(got) == 5
+    lo_e.finish_grads()
+    worst = {k: (got[k] - g).norm().item() / max(g.norm().item(), 1e-12) for k, g in o_grads.items()}
+    for l in range(ocfg.text.num_hidden_layers):
+        for site in SITES:
+            for j, (mod, fin, rws) in enumerate(lo_e.layout[site]):
+                name = f"model.layers.{l}.{mod}"
+                worst[name + ".A"] = (lo_e.grad[(l, site, "A")][j * 64:j * 64 + 8, :fin].cpu() - lo_o.A[name].grad).norm().item() / lo_o.A[name].grad.norm().item()
+                worst[name + ".B"] = (lo_e.grad[(l, site, "B")][rws][:, j * 64:j * 64 + 8].cpu() - lo_o.B[name].grad).norm().item() / lo_o.B[name].grad.norm().item()
+    assert max(worst.values()) < 3e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    extra = tr.non_lora_trainables()
+    assert set(extra) == {"base_model.model." + k for k in o_grads}

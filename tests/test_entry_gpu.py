@@ -227,6 +227,14 @@ def test_train_sft_sh_lora_recipe_then_merge_then_full_fine_tune(tmp_path):
     assert torch.equal(got["visual.blocks.0.attn.qkv.weight"], base_sd["visual.blocks.0.attn.qkv.weight"])            # the tower stayed frozen
     steps3, err3 = launch(env2, *full, "--max_steps", "3")
     assert "resumed from" in err3 and [s["step"] for s in steps3] == [3]
+    # two ranks through the same shell entry (both on this GPU, gloo collectives): rows sharded batch by batch, the adapters' gradient
+    # bucket averaged, rank 0 writes the adapters
+    env3 = dict(env, OUTPUT_DIR=str(tmp_path / "out_lora_2ranks"), NUM_DEVICES="2", GLOBAL_BATCH_SIZE="2", VR2_DIST_BACKEND="gloo", MASTER_PORT="29533")
+    steps4, err4 = launch(env3, *small, "--max_steps", "2")
+    assert [s["step"] for s in steps4] == [1, 2], err4[-3000:]
+    assert "x 2 rank(s)" in err4 and all(np.isfinite(s["loss"]) for s in steps4) and steps4[1]["grad_norm"] > 0
+    ad2 = load_file(str(tmp_path / "out_lora_2ranks" / "adapter_model.safetensors"))
+    assert len(ad2) == 28 and float(ad2["base_model.model.model.layers.0.mlp.gate_proj.lora_B.weight"].abs().max()) > 0
 
 
 def test_train_grpo_sh_with_lora_adapters(tmp_path):

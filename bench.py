@@ -7,15 +7,16 @@ bench.py --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the e
 -- this process starts them itself as a child `python -m torch.distributed.run` (as the reference launches its trainer,
 /root/reference/train/scripts/train_grpo.sh:41) and only forwards the one JSON line; the parent never touches the GPU.
 
-A "step" = one optimiser step = one pass of the hot path over P prompt groups per rank (default P = 16: the reference's
-per_device_train_batch_size x gradient_accumulation_steps in completions / G; 16 groups of G = 8 are the 128 rows one decode
-weight pass serves, so the weights are streamed once per token for all of them), inputs resident in HBM:
+A "step" = one optimiser step = one pass of the hot path over P prompt groups per rank (default P = 22: the reference's
+per_device_train_batch_size x gradient_accumulation_steps in completions / G; 22 groups of G = 8 = 176 sequences share ONE decode
+weight pass -- the register-ring GEMV serves up to 256 rows, and a 176-row token costs 1.19x a 128-row one for 1.375x the
+sequences; P = 32 is 9.7 % faster still per sample but makes the driver's 25-step run 1.7x as long), inputs resident in HBM:
   ViT encode (32 frames) -> LM prefill (once) -> shared-prefix decode of G=8 completions x C new tokens (hipGraph) ->
   reference-model log-probs over the unified [prompt | completions] rows -> policy training forward (log-probs, activations saved) -> group
   advantages -> GRPO loss -> backward -> gradient all-reduce (N>1) -> global-norm clip + AdamW.
 `value` = completions produced by all ranks / wall time of the K timed steps (max over ranks).
 Prints ONE JSON line on rank 0 with `roofline` = the kernel with the largest share of the step's kernel time in the tracked
-rocprofv3 summary (profiles/*kernel_stats_default_bench_p16.md: `gemm256_kernel<4>`, the gate/up GEMM + SwiGLU of the training /
+rocprofv3 summary (profiles/*kernel_stats_default_bench_p22.md: `gemm256_kernel<4>`, the gate/up GEMM + SwiGLU of the training /
 scoring passes, MFMA-bound), timed with HIP events on the engine's stream; `roofline_decode*` = the decode phase's weight-streaming
 GEMVs (HBM-bound), `roofline_wgrad` = the largest weight-gradient GEMM; and `cpu_baseline` (the CPU oracle = "port", rank 0,
 N=1 only: a bounded sample, or the whole step with --cpu-baseline full at config 1's size).  PMC figures (`traffic`, MFMA-busy)
@@ -101,9 +102,12 @@ def parse():
                         "never emit EOS): sequence lengths drawn uniform:LO:HI per sequence (seeded); the decode stops at the "
                         "longest one (rounded up to the engine's 64-step EOS check) and the scoring / training passes run on the "
                         "packed rows.  'off' skips it.  Never part of `value`.")
-    p.add_argument("--prompts-per-gpu", type=int, default=16,
+    p.add_argument("--prompts-per-gpu", type=int, default=None,
                    help="prompt groups per GPU per optimiser step (the reference's per_device_train_batch_size x "
-                        "gradient_accumulation_steps); groups are decoded together, P*G <= 128 rows per weight pass")
+                        "gradient_accumulation_steps); groups are decoded together, P*G <= 256 rows per weight pass (128 with fp8 decode "
+                        "weights).  Default: 22 at the headline workload (bf16 decode weights, <= 32 frames), else 16; clamped to the row limit")
+    p.add_argument("--prompt-pool-gb", type=float, default=9.0,
+                   help="HBM for the resident synthetic prompts: distinct prompts for every step while they fit, else a cyclic pool")
     return p.parse_args()
 
 
@@ -346,7 +350,16 @@ def main():
     from video_r2_amd.train import Trainer
     upd = None if a.no_update else Trainer(eng, pol, grad_exchange=a.grad_exchange)       # fp32 masters + Adam moments + transposed packed copies
     P = a.prompts_per_gpu
-    n_prompts = (a.steps + a.warmup + 1) * P + 2            # + one instrumented step for the phase split + 2 recipe-shaped steps
+    if P is None:          # 176 sequences per decode weight pass at the headline workload; the longer-prompt / fp8 configs keep 128
+        P = 22 if (a.decode_weights == "bf16" and a.frames <= 32) else 16
+    P = max(1, min(P, (128 if a.decode_weights != "bf16" else 256) // G))
+    # synthetic prompts resident before the timed region: distinct ones for every step while they fit --prompt-pool-gb (19 MB of fp32
+    # pixel rows per 32-frame prompt), else a pool of that many steps' worth walked cyclically (every step still runs all of its
+    # work: nothing is cached between steps, and the weights have moved by the time a prompt comes round again)
+    need_steps = a.steps + a.warmup + 1                     # + one instrumented step for the phase split
+    per_step_bytes = P * (a.frames // 2) * 256 * 1176 * 4
+    pool_steps = max(2, min(need_steps, int(a.prompt_pool_gb * 1e9 // max(1, per_step_bytes))))
+    n_prompts = pool_steps * P + 2                          # + 2 recipe-shaped steps
     prompts = [synth_prompt(cfg, a.frames, rank * 1000 + i, device) for i in range(n_prompts)]
     slots = eng.prefix_slots(P, max(len(p[2]) for p in prompts), tag="pol")
     torch.cuda.synchronize()
@@ -355,7 +368,7 @@ def main():
         """One GRPO step over this rank's P prompt groups.  rec(name) marks a phase boundary (instrumented extra step only).
         lens (host ints, one per sequence): emulated EOS positions -- see --eos-mix (Engine.decode finish_at=)."""
         mark = rec if rec is not None else (lambda name: None)
-        mine = prompts[i * P:(i + 1) * P] if mine is None else mine
+        mine = prompts[(i % pool_steps) * P:(i % pool_steps + 1) * P] if mine is None else mine
         Pn = len(mine)
 
         # the step's P clips go through the vision tower in ONE pass and its P prompts through ONE policy prefill and ONE
@@ -593,7 +606,7 @@ def main():
         k_ms, k_how = timed_launches(gu)
         alg = 2 * I * H * (1 if fp8r else 2) + (2 * I * 4 if fp8r else 0) + NG * H * (1 if a8 else 2) + NG * I * 2
         ach = alg / (k_ms * 1e-3) / 1e9
-        mbs = 2 if NG <= 32 else 4 if NG <= 64 else 8
+        mbs = 2 if NG <= 32 else 4 if NG <= 64 else 8 if NG <= 128 else 10 if NG <= 160 else 12 if NG <= 192 else 14 if NG <= 224 else 16
         if a8:
             kname = "gemv_ring8_kernel<1, %d, 1> (fp8 activations x fp8 weights, v_mfma_f32_16x16x32_fp8_fp8)" % mbs
         elif fp8r:
@@ -672,7 +685,7 @@ def main():
                 "mfma_busy_pct": pg.get("mfma_busy_pct") if pg else None,
                 "algorithmic_bytes_per_launch": 2.0 * (Tr * H + n_gu * H + Tr * (n_gu // 2)),
                 "avg_launch_us": g_ms * 1e3, "algorithmic_flops_per_launch": 2.0 * Tr * n_gu * H,
-                "dominant_by": "profiles/r04_kernel_stats_default_bench_p16.md (largest share of the step's kernel time)"}
+                "dominant_by": "profiles/r04_kernel_stats_default_bench_p22.md (largest share of the step's kernel time)"}
         # the weight-gradient GEMM of the same layer (dW[2I][H] += dY[T][2I]^T X[T][H]): the largest launch of the backward
         if hasattr(upd, "state") and "l0.gu_w" in getattr(upd.state, "grad", {}):
             # operands = the step's own buffers (dY: the gate/up pre-activation gradients the last backward left in its workspace,
@@ -713,7 +726,7 @@ def main():
                                                                              else "bf16 (decode: fp8 e4m3 weights per channel x fp8 activations per row on the fp8 MFMA)") if a.decode_weights == "fp8"
                                                                             else "bf16 (decode weights fp8 e4m3, per-channel scales)"), "data": "synthetic",
             "config": {"workload": f"Qwen2.5-VL-{a.model.upper()} {a.frames} frames 224^2, G={G}, {C} new tokens, {P} prompt group(s) per GPU per step",
-                       "prompts_per_gpu_per_step": P,
+                       "prompts_per_gpu_per_step": P, "prompt_pool_steps": pool_steps,
                        "prompt_tokens": 32 * a.frames + 64, "weights": "random-init seed 0, bf16",
                        "phases_timed": ["vit", "prefill", "decode(G x C, sampling T=0.9 top-k 50, EOS off)",
                                         "ref prefill + ref log-probs", "policy training forward", "advantages + GRPO loss"]

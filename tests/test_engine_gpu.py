@@ -161,11 +161,12 @@ def test_multi_group_decode_matches_single_group():
     t1, _ = eng.decode(eng.text, states, G, C, seed=5, use_graph=True)
     t2, _ = eng.decode(eng.text, states, G, C, seed=5, use_graph=True)
     assert torch.equal(t1, t2)
-    with pytest.raises(ValueError, match="at most 128 rows"):
-        eng.decode(eng.text, states, 65, C)
+    with pytest.raises(ValueError, match="at most 256 rows"):
+        eng.decode(eng.text, states, 129, C)
     # more than 16 rows: the LDS-staged GEMV with a different split-K -> same logits up to fp32 summation order; 40 rows
     # (16-row blocks MB = 4) and the full 128 rows (MB = 8, two k groups)
-    for G2 in (20, 64):
+    # 80 / 128 sequences per group: 160 / 256 rows, the ring GEMV's 12- and 16-row-block instantiations (round 4)
+    for G2 in (20, 64, 80, 128):
         forced2 = torch.randint(10, 2000, (2 * G2, C), generator=g).numpy()
         singles2 = []
         for i in range(2):

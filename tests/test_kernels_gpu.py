@@ -173,7 +173,8 @@ def test_gemm_main_plus_tail_split(dev, K):
     assert (gu.float().cpu() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item() + 1e-5
 
 
-@pytest.mark.parametrize("M,N,K,ns", [(8, 4608, 3584, 1), (8, 3584, 18944, 4), (4, 512, 512, 2), (16, 2048, 1152, 1), (1, 20, 128, 1), (3, 48, 160 + 32, 1), (7, 152064, 3584, 1), (32, 4608, 3584, 4), (17, 528, 1152, 2)])
+@pytest.mark.parametrize("M,N,K,ns", [(8, 4608, 3584, 1), (8, 3584, 18944, 4), (4, 512, 512, 2), (16, 2048, 1152, 1), (1, 20, 128, 1), (3, 48, 160 + 32, 1), (7, 152064, 3584, 1), (32, 4608, 3584, 4), (17, 528, 1152, 2),
+                                      (160, 4608, 3584, 4), (192, 3584, 18944, 8), (256, 3584, 3584, 4), (250, 1000, 1152, 1), (140, 528, 1152, 2), (210, 4608, 3584, 4)])
 def test_gemv(dev, M, N, K, ns):
     g = torch.Generator().manual_seed(N + K)
     x = bf(torch.randn(M, K, generator=g))
@@ -203,7 +204,7 @@ def test_gemm_swiglu_epilogue(dev):
 
 
 def test_gemv_exact_and_gateup(dev):
-    for Mx in (5, 27, 50, 64, 100, 128):         # every activation-block width (M <= 16, 32, 64, 128)
+    for Mx in (5, 27, 50, 64, 100, 128, 150, 192, 220, 256):         # every activation-block width (M <= 16, 32, 64, 128, 160, 192, 224, 256)
         _gateup_case(dev, Mx)
 
 

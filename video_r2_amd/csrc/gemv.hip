@@ -312,16 +312,18 @@ __global__ __launch_bounds__(256 * KS) void gemv_lds_kernel(const bf16* __restri
 //     reads stale data), so up to D of its load batches name chunks past the end of the part: they re-read the last chunk.
 typedef __attribute__((ext_vector_type(4))) float wreg;    // 16 B of bf16x8 weight / activation fragment in 4 VGPRs
 
+// MB > 8 (129-256 rows, round 4): 2 x MB accumulator sets + MB activation fragments per wave do not fit the 128 registers of
+// two workgroups per CU; the grid is one workgroup per CU anyway (ring_groups), so those instantiations ask for one.
 template <int MODE, int MB, int D, int ABL = 0>   // ABL: ablations for profiles/ (1 no x staging, 2 no LDS reads / MFMA, 3 no weight stream, 4 = 1 + 3)
-__global__ __launch_bounds__(512, 2) void gemv_ring_kernel(const bf16* __restrict__ x, int ldx, int xadv, int M,
+__global__ __launch_bounds__(512, (MB > 8 ? 1 : 2)) void gemv_ring_kernel(const bf16* __restrict__ x, int ldx, int xadv, int M,
                                                            const bf16* __restrict__ Wp, int n_tiles, int N, int K,
                                                            float* __restrict__ out_f32, long split_stride, int ldo,
                                                            bf16* __restrict__ out_bf16) {
   constexpr int NB = D + 1;                          // LDS ring slots == weight register sets
-  static_assert(MB >= 2 && (NB & (NB - 1)) == 0, "ring shape");
+  static_assert(MB >= 2 && MB <= 16 && (NB & (NB - 1)) == 0, "ring shape (lgkmcnt counts <= 15 fragment reads)");
   constexpr int CHUNKB = MB * 2048;                  // 16*MB rows x 64 k bf16
   constexpr int PIECES = MB * 2;                     // 1-KiB pieces (8 rows x 128 B) of an x chunk
-  constexpr int XP = PIECES >= 8 ? PIECES / 8 : 1;   // pieces staged per wave and chunk (MB = 2: waves 4-7 repeat 0-3)
+  constexpr int XP = (PIECES + 7) / 8;               // pieces staged per wave and chunk (MB = 2, 10, 14: some waves repeat a piece)
   extern __shared__ __attribute__((aligned(16))) char xring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -510,6 +512,8 @@ void launch_gemv(dim3 grid, hipStream_t st, const bf16* x, int ldx, int M, const
     const int abl = vr2_tune_get(VR2_TUNE_GEMV_ABLATE);
     if (abl > 0 && MODE == 1 && M > 64) {            // profiles/: which resource bounds the kernel (results are wrong)
       if (abl == 1) VR2_RING_LAUNCH(8, 1, 1); else if (abl == 2) VR2_RING_LAUNCH(8, 1, 2); else if (abl == 3) VR2_RING_LAUNCH(8, 1, 3); else VR2_RING_LAUNCH(8, 1, 4);
+    } else if (M > 128) {                            // 129-256 rows: 10 / 12 / 14 / 16 row blocks per wave, one chunk in flight
+      if (M <= 160) VR2_RING_LAUNCH(10, 1); else if (M <= 192) VR2_RING_LAUNCH(12, 1); else if (M <= 224) VR2_RING_LAUNCH(14, 1); else VR2_RING_LAUNCH(16, 1);
     } else if (variant == 2) {                       // shallow ring (2 slots, one chunk in flight): A/B reference point
       if (M <= 32) VR2_RING_LAUNCH(2, 1); else if (M <= 64) VR2_RING_LAUNCH(4, 1); else VR2_RING_LAUNCH(8, 1);
     } else {
@@ -518,6 +522,7 @@ void launch_gemv(dim3 grid, hipStream_t st, const bf16* x, int ldx, int M, const
 #undef VR2_RING_LAUNCH
     return;
   }
+  if (M > 128) { vr2_set_error("decode GEMV: %d rows need the ring kernel (K %% 64 == 0, >= 4 chunks per k part)", M); return; }
   // LDS-staged variant, 8 weight tiles (128 output rows) per workgroup; two k groups per workgroup when the part is long
   const dim3 g4((unsigned)((n_tiles + 7) / 8), grid.y);
   // (measured at M = 64, 7B shapes: the second k group pays off for the split-K projections -- down 37 -> 31.5 us at 8 slabs,
@@ -548,7 +553,8 @@ void launch_gemv(dim3 grid, hipStream_t st, const bf16* x, int ldx, int M, const
 
 extern "C" int vr2_gemv_bf16(const void* x, int64_t ldx, int64_t M, const void* Wpacked, int64_t N, int64_t K,
                              void* out_f32, int64_t split_stride, int64_t ldo, int nsplit, void* stream) {
-  VR2_REQUIRE(M >= 1 && M <= 128, "vr2_gemv_bf16: M=%ld must be in [1,128]", (long)M);
+  VR2_REQUIRE(M >= 1 && M <= 256, "vr2_gemv_bf16: M=%ld must be in [1,256]", (long)M);
+  VR2_REQUIRE(M <= 128 || (K % 64 == 0 && (K / 64) / nsplit >= 4), "vr2_gemv_bf16: M=%ld > 128 rows needs K %% 64 == 0 and >= 4 chunks per part", (long)M);
   VR2_REQUIRE(K % 32 == 0 && N % 4 == 0, "vr2_gemv_bf16: K=%ld %% 32 and N=%ld %% 4 must be 0", (long)K, (long)N);
   VR2_REQUIRE(ldx % 8 == 0 && ldo % 4 == 0, "vr2_gemv_bf16: strides must keep 16-byte alignment");
   VR2_REQUIRE(nsplit >= 1 && (K / 32) >= (int64_t)nsplit * 4, "vr2_gemv_bf16: nsplit=%d too large for K=%ld", nsplit, (long)K);
@@ -561,7 +567,8 @@ extern "C" int vr2_gemv_bf16(const void* x, int64_t ldx, int64_t M, const void* 
 
 extern "C" int vr2_gemv_gateup_silu_bf16(const void* x, int64_t ldx, int64_t M, const void* Wpacked, int64_t I,
                                          int64_t K, void* act_bf16, int64_t ldo, void* stream) {
-  VR2_REQUIRE(M >= 1 && M <= 128, "vr2_gemv_gateup_silu_bf16: M=%ld must be in [1,128]", (long)M);
+  VR2_REQUIRE(M >= 1 && M <= 256, "vr2_gemv_gateup_silu_bf16: M=%ld must be in [1,256]", (long)M);
+  VR2_REQUIRE(M <= 128 || (K % 64 == 0 && K >= 256), "vr2_gemv_gateup_silu_bf16: M=%ld > 128 rows needs K %% 64 == 0", (long)M);
   VR2_REQUIRE(K % 32 == 0 && K >= 128 && I % 16 == 0, "vr2_gemv_gateup_silu_bf16: K=%ld %% 32 (>=128) and I=%ld %% 16 must be 0", (long)K, (long)I);
   VR2_REQUIRE(ldx % 8 == 0 && ldo % 4 == 0, "vr2_gemv_gateup_silu_bf16: strides must keep alignment");
   const int it = (int)(I / 16);

@@ -722,6 +722,8 @@ class Engine:
         def pick(k, want):
             while want > 1 and (k // 32) < want * 4:
                 want //= 2
+            while G > 128 and want > 1 and (k // 64) < want * 4:     # above 128 rows only the ring kernel runs: >= 4 whole 64-k chunks per part
+                want //= 2
             return want
         # (M <= 16: 32-row workgroups with 4 k-splitting waves; M > 16: the LDS-staged variant covers 128 output rows per
         # workgroup with 2 k groups -> the same slab count for q/k/v and o, twice for down)
@@ -755,11 +757,17 @@ class Engine:
         )
         return b
 
+    def max_decode_rows(self):
+        """sequences per decode weight pass: 256 on bf16 weights (round 4: the register-ring GEMV with 12 / 16 row blocks per wave;
+        at 256 rows a token costs ~1.5x a 128-row token, so two groups' worth of sequences share one stream of the weights), 128 on
+        the fp8 copies (their kernels stop there)"""
+        return 128 if self.decode_fp8 else 256
+
     @_on_stream
     def decode(self, W: Params, st, G, max_new_tokens, temperature=0.9, top_k=50, seed=0, eos_token_id=None,
                use_graph=True, forced_tokens=None, check_every=64, top_p=1.0, min_p=None, repetition_penalty=1.0, finish_at=None):
         """Sample G completions per prompt group of up to max_new_tokens.  ``st``: one PromptState, or a list of P states whose
-        prefix KV live in ``prefix_slots`` (P prompt groups decoded together: P*G <= 128 rows per weight pass, so the weights
+        prefix KV live in ``prefix_slots`` (P prompt groups decoded together: P*G <= max_decode_rows() rows per weight pass, so the weights
         are streamed once for all of them).  -> (int32 [P*G, C'] device, buffers).
         eos_token_id=None disables EOS (fixed length).  forced_tokens [P*G,C] (host ints) teacher-forces the inputs
         (the sampled tokens are still produced, from the same logits, for comparison).
@@ -777,8 +785,9 @@ class Engine:
         states = st if isinstance(st, (list, tuple)) else [st]
         P = len(states)
         NG = P * G
-        if NG > 128:
-            raise ValueError(f"{P} groups x {G} sequences = {NG} rows; the decode GEMV handles at most 128 rows per pass")
+        if NG > self.max_decode_rows():
+            raise ValueError(f"{P} groups x {G} sequences = {NG} rows; the decode GEMV handles at most {self.max_decode_rows()} rows per pass"
+                             + (" with fp8 decode weights" if self.decode_fp8 else ""))
         C = int(max_new_tokens)
         k0, v0 = states[0].prefix_k, states[0].prefix_v
         cap_s = k0.stride(0) // k0.stride(1)             # row capacity of the prefix cache: the graph is shaped for it

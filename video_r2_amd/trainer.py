@@ -196,7 +196,7 @@ class QwenGRPOTrainer:
         self._textual_logs = []
 
     # ------------------------------------------------------------------ rollout + scoring for this rank's prompt groups
-    MAX_DECODE_ROWS = 128      # sequences per decode weight pass (Engine.decode): G * groups-per-chunk stays below it
+    MAX_DECODE_ROWS = None     # sequences per decode weight pass; None = Engine.max_decode_rows() (256 on bf16 weights, 128 on fp8 copies)
 
     def _clips(self, pi):
         """the clips of one processed example as Engine.encode_videos wants them"""
@@ -225,7 +225,7 @@ class QwenGRPOTrainer:
         a, m = self.args, self.model
         eng = m.engine
         G = self.local_generations              # sequences THIS rank generates per prompt group (num_generations unless ranks share a group)
-        per = max(1, self.MAX_DECODE_ROWS // G)
+        per = max(1, (self.MAX_DECODE_ROWS or eng.max_decode_rows()) // G)
         groups = []
         pending = None
         for c0 in range(0, len(examples), per):

@@ -9,7 +9,7 @@
 # num_generations / per_device ranks, each generating its slice of the completions; rewards are gathered and the advantages
 # taken over the whole group -- on 8 GPUs that is ONE prompt per optimiser step, the reference's batch.  For throughput raise
 # per_device_train_batch_size to num_generations * P: P groups per GPU are decoded together (the decode streams the weights
-# once for up to 128 sequences; a 1-row decode streams them for a single sequence).
+# once for up to 256 sequences; a 1-row decode streams them for a single sequence).
 #
 # Rewards: the functions are looked up by name in --reward_module (default: your src/train/reward_funcs.py next to this
 # entry point if it imports, else the engine's built-in accuracy / format rewards).  The temporal-grounding reward named

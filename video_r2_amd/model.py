@@ -245,12 +245,13 @@ class VideoR2Model:
         warp = dict(top_p=gc.top_p if gc.do_sample else 1.0, min_p=gc.min_p if gc.do_sample else None,
                     repetition_penalty=gc.repetition_penalty)    # (the penalty is a processor: HF applies it to greedy decoding too)
         eos = gc.eos_token_id if gc.eos_token_id is not None else cfg.eos_token_id
-        uniform = len(groups) > 1 and len({n for _, n, _ in groups}) == 1 and groups[0][1] * 2 <= 128
+        rows_max = self.engine.max_decode_rows()      # sequences per decode weight pass (256 on bf16 weights)
+        uniform = len(groups) > 1 and len({n for _, n, _ in groups}) == 1 and groups[0][1] * 2 <= rows_max
         if uniform:
             # every prompt has the same number of copies: prefill the groups into shared-stride prefix slots and decode them
-            # TOGETHER, up to 128 sequences per weight pass (the decode is weight-streaming bound)
+            # TOGETHER, up to rows_max sequences per weight pass (the decode is weight-streaming bound)
             n = groups[0][1]
-            per = max(1, 128 // n)
+            per = max(1, rows_max // n)
             for c0 in range(0, len(groups), per):
                 chunk = groups[c0:c0 + per]
                 slots = self.engine.prefix_slots(len(chunk), max(len(g_[2]) for g_ in chunk), tag="pol") if len(chunk) > 1 else [None]

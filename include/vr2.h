@@ -22,7 +22,7 @@ extern "C" {
 const char* vr2_last_error(void);
 int vr2_version(void);
 /* launch-time kernel-variant knobs for A/B measurements (defaults = the measured best).  key 0: decode GEMV for 16 < M <= 128
- * rows (0 = LDS-staged kernel of round 1, 1 = one-workgroup-per-CU register-ring kernel with 3 weight chunks in flight per wave,
+ * rows -- above 128 rows, up to 256, the register-ring kernel always runs -- (0 = LDS-staged kernel of round 1, 1 = one-workgroup-per-CU register-ring kernel with 3 weight chunks in flight per wave,
  * 2 = the same with 1: the default).  key 1: ablations of that kernel for profiles/ (results wrong).  key 2: x is chunk-major.
  * keys 3 / 4: K/V tiles a decode-attention suffix wave / shared-prefix workgroup keeps in flight in registers (1-4 / 1-3; defaults
  * 2 / 1, profiles/r04_attn_decode_depth.md). */
@@ -55,7 +55,7 @@ int vr2_gemm_bf16(const void* A_bf16, int64_t lda, const void* W_packed_bf16, co
  * determinism).  ptr = NULL, bytes = 0 unregisters. */
 int vr2_set_gemm_workspace(void* ptr, int64_t bytes);
 
-/* Decode-step weight streaming for M <= 64 rows: out[s][m][n] = sum over K-slice s of x[m][k] W[n][k] (fp32 partial
+/* Decode-step weight streaming for M <= 256 rows (above 128: K % 64 == 0 and >= 4 chunks of 64 k per part): out[s][m][n] = sum over K-slice s of x[m][k] W[n][k] (fp32 partial
  * slabs, summed by the consumer).  Replaces the 1-token forward of HF generate, generation/utils.py:2876-2937 (K11
  * decode rows, K14 lm_head). */
 int vr2_gemv_bf16(const void* x_bf16, int64_t ldx, int64_t M, const void* W_packed_bf16, int64_t N, int64_t K,

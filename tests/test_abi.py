@@ -40,8 +40,10 @@ def test_argument_validation_without_gpu():
     l = lib.load()
     rc = l.vr2_gemm_bf16(None, 8, None, None, None, 8, 4, 8, 100, 0, None)
     assert rc != 0 and b"multiple of 64" in l.vr2_last_error()
-    rc = l.vr2_gemv_bf16(None, 8, 129, None, 16, 128, None, 0, 16, 1, None)
-    assert rc != 0 and b"[1,128]" in l.vr2_last_error()
+    rc = l.vr2_gemv_bf16(None, 8, 257, None, 16, 128, None, 0, 16, 1, None)
+    assert rc != 0 and b"[1,256]" in l.vr2_last_error()
+    rc = l.vr2_gemv_bf16(None, 8, 129, None, 16, 128, None, 0, 16, 1, None)      # above 128 rows only the ring kernel runs: whole 64-k chunks, >= 4 per part
+    assert rc != 0 and b"> 128 rows needs" in l.vr2_last_error()
     rc = l.vr2_attn_tok(None, 1, None, 8, None, None, None, None, 8, None, 8, 4, 2, 64, 1.0, None, None)
     assert rc != 0 and b"head_dim" in l.vr2_last_error()
 

@@ -105,7 +105,7 @@ def parse():
     p.add_argument("--prompts-per-gpu", type=int, default=None,
                    help="prompt groups per GPU per optimiser step (the reference's per_device_train_batch_size x "
                         "gradient_accumulation_steps); groups are decoded together, P*G <= 256 rows per weight pass (128 with fp8 decode "
-                        "weights).  Default: 22 at the headline workload (bf16 decode weights, <= 32 frames), else 16; clamped to the row limit")
+                        "weights).  Default: 22 up to 32 frames (bf16 or fp8 x fp8 decode), else 16; clamped to the row limit (128 for weight-only fp8)")
     p.add_argument("--prompt-pool-gb", type=float, default=9.0,
                    help="HBM for the resident synthetic prompts: distinct prompts for every step while they fit, else a cyclic pool")
     return p.parse_args()
@@ -351,8 +351,8 @@ def main():
     upd = None if a.no_update else Trainer(eng, pol, grad_exchange=a.grad_exchange)       # fp32 masters + Adam moments + transposed packed copies
     P = a.prompts_per_gpu
     if P is None:          # 176 sequences per decode weight pass at the headline workload; the longer-prompt / fp8 configs keep 128
-        P = 22 if (a.decode_weights == "bf16" and a.frames <= 32) else 16
-    P = max(1, min(P, (128 if a.decode_weights != "bf16" else 256) // G))
+        P = 22 if (a.decode_weights != "fp8w" and a.frames <= 32) else 16
+    P = max(1, min(P, (128 if a.decode_weights == "fp8w" else 256) // G))
     # synthetic prompts resident before the timed region: distinct ones for every step while they fit --prompt-pool-gb (19 MB of fp32
     # pixel rows per 32-frame prompt), else a pool of that many steps' worth walked cyclically (every step still runs all of its
     # work: nothing is cached between steps, and the weights have moved by the time a prompt comes round again)
@@ -553,7 +553,7 @@ def main():
         act = eng.buf("d.act", (NG, I), torch.bfloat16)
         reps = 3
         e0, e1 = ev(), ev()
-        fp8r = fp8 and NG <= eng.decode_fp8_max_rows         # above that the engine decodes with the bf16 kernels
+        fp8r = fp8 and NG <= (256 if eng.decode_fp8_act else eng.decode_fp8_max_rows)   # above that the engine decodes with the bf16 kernels
         a8 = fp8r and eng._a8w8(pol, "l0.gu_w", NG)           # fp8 activations on the fp8 MFMA (> 16 rows)
         if a8:
             xq8, xqs = eng._quant(xn, NG, H)                  # quantised once, outside the timed launches

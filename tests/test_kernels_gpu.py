@@ -671,7 +671,7 @@ def test_quant_rows_fp8_matches_torch_e4m3(dev, M, K):
     assert torch.all(_deinterleave_fp8_rows(q8.cpu(), k64)[:, K:] == 0)
 
 
-@pytest.mark.parametrize("M", [20, 64, 128])
+@pytest.mark.parametrize("M", [20, 64, 128, 150, 176, 220, 256])
 def test_gemv_fp8_activations_on_the_fp8_mfma(dev, M):
     """vr2_gemv_a8w8 / vr2_gemv_gateup_silu_a8w8 (v_mfma_f32_16x16x32_fp8_fp8): against the matmul of the DEQUANTISED operands in
     float64 -- the products of two e4m3 values are exact in fp32, only the summation order differs -- for a ragged N, split-K

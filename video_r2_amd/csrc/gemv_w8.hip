@@ -452,7 +452,7 @@ void launch_w8(dim3 grid, hipStream_t st, const bf16* x, int ldx, int M, const u
 #undef VR2_W8_LAUNCH
 }
 
-// ---- fp8 activations x fp8 weights on the fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8), 16 < M <= 128 rows, K % 128 == 0 --------
+// ---- fp8 activations x fp8 weights on the fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8), 16 < M <= 256 rows, K % 128 == 0 --------
 // BASELINE config 5 ("fp8 weights on CDNA4 fp8 MFMA").  Same one-workgroup-per-CU ring structure as gemv.hip's
 // gemv_ring_kernel (read its header comment first); what differs:
 //   * the weight tiles are the 16-row x 64-k fp8 tiles above: one 16-B load per lane = the A operands of TWO MFMA k-steps, so a
@@ -468,17 +468,17 @@ void launch_w8(dim3 grid, hipStream_t st, const bf16* x, int ldx, int M, const u
 typedef __attribute__((ext_vector_type(4))) float wreg8;
 typedef __attribute__((ext_vector_type(2))) long l64x2;
 
-template <int MODE, int MB, int D>
-__global__ __launch_bounds__(512, 2) void gemv_ring8_kernel(const unsigned char* __restrict__ x8, int ldx8,
+template <int MODE, int MB, int D>   // MB > 8 (129-256 rows): one workgroup per CU with the whole register file, as gemv.hip's ring kernel
+__global__ __launch_bounds__(512, (MB > 8 ? 1 : 2)) void gemv_ring8_kernel(const unsigned char* __restrict__ x8, int ldx8,
                                                             const float* __restrict__ xscale, int M,
                                                             const unsigned char* __restrict__ Wp, const float* __restrict__ wscale,
                                                             int n_tiles, int N, int K, float* __restrict__ out_f32,
                                                             long split_stride, int ldo, bf16* __restrict__ out_bf16) {
   constexpr int NB = D + 1;
-  static_assert(MB >= 2 && (NB & (NB - 1)) == 0, "ring shape");
+  static_assert(MB >= 2 && MB <= 16 && (NB & (NB - 1)) == 0, "ring shape (lgkmcnt counts <= 15 fragment reads)");
   constexpr int CHUNKB = MB * 2048;                  // 16*MB rows x 128 k fp8
   constexpr int PIECES = MB * 2;                     // 1-KiB pieces (16 rows x 64 B) of an x chunk: [half][16-row block]
-  constexpr int XP = PIECES >= 8 ? PIECES / 8 : 1;
+  constexpr int XP = (PIECES + 7) / 8;               // (MB = 2, 10, 14: some waves repeat a piece)
   extern __shared__ __attribute__((aligned(16))) char xring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -696,7 +696,8 @@ int launch_a8w8(const void* x8, int64_t ldx8, const void* xscale, int64_t M, con
                        (const unsigned char*)x8, (int)ldx8, (const float*)xscale, (int)M, (const unsigned char*)W8,             \
                        (const float*)wscale, n_tiles, N, (int)K, of, split_stride, ldo, ob);                                    \
   } while (0)
-  if (M <= 32) VR2_RING8(2); else if (M <= 64) VR2_RING8(4); else VR2_RING8(8);
+  if (M <= 32) VR2_RING8(2); else if (M <= 64) VR2_RING8(4); else if (M <= 128) VR2_RING8(8);
+  else if (M <= 160) VR2_RING8(10); else if (M <= 192) VR2_RING8(12); else if (M <= 224) VR2_RING8(14); else VR2_RING8(16);
 #undef VR2_RING8
   return 0;
 }
@@ -719,7 +720,7 @@ extern "C" int vr2_quant_rows_fp8(const void* x_bf16, int64_t ldx, int64_t M, in
 extern "C" int vr2_gemv_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64_t M, const void* Wpacked_fp8,
                              const void* wscale_f32, int64_t N, int64_t K, void* out_f32, int64_t split_stride, int64_t ldo,
                              int nsplit, void* stream) {
-  VR2_REQUIRE(M > 16 && M <= 128, "vr2_gemv_a8w8: M=%ld must be in (16,128]", (long)M);
+  VR2_REQUIRE(M > 16 && M <= 256, "vr2_gemv_a8w8: M=%ld must be in (16,256]", (long)M);
   VR2_REQUIRE(K % 128 == 0 && N % 4 == 0 && ldx8 % 16 == 0 && ldx8 >= K && ldo % 4 == 0, "vr2_gemv_a8w8: K=%ld %% 128, N=%ld %% 4, strides", (long)K, (long)N);
   VR2_REQUIRE(nsplit >= 1 && (K / 128) >= (int64_t)nsplit, "vr2_gemv_a8w8: nsplit=%d too large for K=%ld", nsplit, (long)K);
   const int n_tiles = (int)((N + 15) / 16);
@@ -730,7 +731,7 @@ extern "C" int vr2_gemv_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale
 
 extern "C" int vr2_gemv_gateup_silu_a8w8(const void* x_fp8, int64_t ldx8, const void* xscale_f32, int64_t M, const void* Wpacked_fp8,
                                          const void* wscale_f32, int64_t I, int64_t K, void* act_bf16, int64_t ldo, void* stream) {
-  VR2_REQUIRE(M > 16 && M <= 128, "vr2_gemv_gateup_silu_a8w8: M=%ld must be in (16,128]", (long)M);
+  VR2_REQUIRE(M > 16 && M <= 256, "vr2_gemv_gateup_silu_a8w8: M=%ld must be in (16,256]", (long)M);
   VR2_REQUIRE(K % 128 == 0 && I % 16 == 0 && ldx8 % 16 == 0 && ldx8 >= K && ldo % 4 == 0, "vr2_gemv_gateup_silu_a8w8: bad shape");
   const int it = (int)(I / 16);
   if (launch_a8w8<1>(x_fp8, ldx8, xscale_f32, M, Wpacked_fp8, wscale_f32, 2 * it, (int)I, K, (float*)nullptr, 0L, (int)ldo,

@@ -189,7 +189,7 @@ class Engine:
         """(packed fp8 weights, scales) when fp8 decode weights are enabled and P carries them (weights.add_fp8_decode_copies).
         Measured decode speed-up over bf16 weights: 1.24-1.33x at 8-64 rows, 1.12x at 128 rows (where the activations' L2 -> LDS
         traffic, not the weight bytes, is most of the load path).  Above decode_fp8_max_rows the bf16 kernels are used."""
-        if not self.decode_fp8 or rows > self.decode_fp8_max_rows:
+        if not self.decode_fp8 or rows > (256 if self.decode_fp8_act else self.decode_fp8_max_rows):
             return None
         f8 = getattr(P, "f8", None)
         if not f8 or wname not in f8:
@@ -204,7 +204,7 @@ class Engine:
 
     def _a8w8(self, P: Params, wname, G):
         """fp8 activations x fp8 weights on the fp8 MFMA: above 16 rows, K a multiple of 128, when the mode is on"""
-        return self.decode_fp8 and self.decode_fp8_act and 16 < G <= self.decode_fp8_max_rows and P.shape[wname][1] % 128 == 0
+        return self.decode_fp8 and self.decode_fp8_act and 16 < G <= 256 and P.shape[wname][1] % 128 == 0
 
     def _qbuf(self, G):
         t = self.cfg.text
@@ -219,7 +219,7 @@ class Engine:
             lib.call("vr2_gemv_a8w8", q8, q8.stride(0), xs, G, f8[0], f8[1], n, kp, out, out.stride(0) if nsplit > 1 else 0,
                      out.stride(-2), nsplit, self.s)
             return
-        if f8 is not None:
+        if f8 is not None and G <= self.decode_fp8_max_rows:      # weight-only fp8 (bf16 activations): up to 128 rows
             lib.call("vr2_gemv_w8", x, x.stride(0), G, f8[0], f8[1], n, kp, out, out.stride(0) if nsplit > 1 else 0,
                      out.stride(-2), nsplit, self.s)
             return
@@ -731,7 +731,7 @@ class Engine:
                                                     # (4,4) 5.03, (2,4) 5.20, (4,10) 4.70, (5,8) 4.73 ms/token (C = 256)
         if os.environ.get("VR2_SPLITS"):                               # measurement override: "q,d"
             wq, wd = (int(v) for v in os.environ["VR2_SPLITS"].split(","))
-        if self.decode_fp8 and G <= self.decode_fp8_max_rows:
+        if self.decode_fp8 and G <= (256 if self.decode_fp8_act else self.decode_fp8_max_rows):
             # fp8 weights: 64-k double steps (direct kernel) / 256-k chunks (staged kernel, no second k group): fewer, longer parts
             def pick(k, want):                     # noqa: F811
                 while want > 1 and (k // 64) < want * 4:
@@ -760,8 +760,8 @@ class Engine:
     def max_decode_rows(self):
         """sequences per decode weight pass: 256 on bf16 weights (round 4: the register-ring GEMV with 12 / 16 row blocks per wave;
         at 256 rows a token costs ~1.5x a 128-row token, so two groups' worth of sequences share one stream of the weights), 128 on
-        the fp8 copies (their kernels stop there)"""
-        return 128 if self.decode_fp8 else 256
+        weight-only fp8 copies (that kernel stops there; fp8 activations x fp8 weights run the same ring structure up to 256)"""
+        return 128 if (self.decode_fp8 and not self.decode_fp8_act) else 256
 
     @_on_stream
     def decode(self, W: Params, st, G, max_new_tokens, temperature=0.9, top_k=50, seed=0, eos_token_id=None,

@@ -263,6 +263,56 @@ def case_generate(name, cfg, seed, n_frames, hw, G, C):
                         hf_step_lse=torch.logsumexp(hf_step_logits / 0.9, -1).numpy())
 
 
+def case_sft(name, cfg, seed, n_frames, hw, sec, spans):
+    """Stage-1 SFT: HF's own loss for `labels` (ForCausalLMLoss: shift by one, mean over the positions whose label is not -100 --
+    the arithmetic of the reference's mixed-modality forward, train/monkey_patch_forward.py:619-631) and HF autograd's gradients of a
+    few tensors, against oracle.sft.sft_loss over oracle forward_logits and torch autograd through the oracle.  spans: [(n tokens,
+    supervised)] appended after the video prompt (user / answer pieces)."""
+    from oracle import sft as osft
+    w = om.make_weights(cfg, seed=seed)
+    m = hf_model(cfg, w)
+    p = synth_prompt(cfg, n_frames, hw, seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    pieces = [(p["input_ids"][0].tolist(), False)]
+    for n, sup in spans:
+        pieces.append((torch.randint(10, cfg.image_token_id - 1, (n,), generator=g).tolist() + ([cfg.eos_token_id] if sup else []), sup))
+    ids_np, labels_np = osft.labels_of(pieces)
+    ids, labels = torch.from_numpy(ids_np)[None], torch.from_numpy(labels_np)[None]
+    px = torch.from_numpy(p["pixel_values_videos"])
+    grid = torch.from_numpy(p["video_grid_thw"])
+    spg = torch.tensor([sec], dtype=torch.float32)
+    m.train(False)
+    for q in m.parameters():
+        q.requires_grad_(True)
+    out = m(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values_videos=px, video_grid_thw=grid, second_per_grid_ts=spg,
+            mm_token_type_ids=mm_types(cfg, ids), labels=labels)
+    hf_loss = out.loss
+    hf_loss.backward()
+    named = dict(m.named_parameters())
+    pick = {"model.norm.weight": "model.language_model.norm.weight", "lm_head.weight": "lm_head.weight",
+            "model.layers.0.self_attn.q_proj.bias": "model.language_model.layers.0.self_attn.q_proj.bias",
+            "model.layers.1.mlp.down_proj.weight": "model.language_model.layers.1.mlp.down_proj.weight",
+            "visual.merger.ln_q.weight": "model.visual.merger.ln_q.weight",
+            "visual.blocks.0.attn.qkv.bias": "model.visual.blocks.0.attn.qkv.bias"}
+    hf_grads = {k: named[v].grad.detach().clone() for k, v in pick.items()}
+    # oracle: the same loss and gradients by autograd through the restatement
+    wt = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    o_logits = om.forward_logits(wt, cfg, ids, None, px, p["video_grid_thw"], [sec])
+    o_loss = osft.sft_loss(o_logits, labels)
+    o_loss.backward()
+    e_loss = abs(float(o_loss) - float(hf_loss))
+    e_g = {k: ((wt[k].grad - hf_grads[k]).norm() / hf_grads[k].norm().clamp(min=1e-12)).item() for k in pick}
+    print(f"[{name}] loss {float(hf_loss):.6f} |oracle - hf| {e_loss:.2e}; gradient rel err {max(e_g.values()):.2e} ({len(ids_np)} tokens, "
+          f"{int((labels_np != -100).sum())} supervised)")
+    assert e_loss < 1e-5 * max(1.0, abs(float(hf_loss))) and max(e_g.values()) < 1e-4, (e_loss, e_g)
+    np.savez_compressed(
+        os.path.join(GOLD, f"{name}.npz"), seed=np.int64(seed), n_frames=np.int64(n_frames), hw=np.asarray(hw), sec=np.float32(sec),
+        group=np.int64(cfg.text.num_attention_heads // cfg.text.num_key_value_heads), frames_u8=p["frames"].astype(np.uint8),
+        video_grid_thw=p["video_grid_thw"], input_ids=ids_np, labels=labels_np, hf_loss=np.float32(float(hf_loss)),
+        hf_lm_head_grad_rows=hf_grads["lm_head.weight"][:64].numpy().astype(np.float32),
+        **{"hf_grad:" + k: (v[:16] if v.dim() == 2 else v).numpy().astype(np.float32) for k, v in hf_grads.items() if k != "lm_head.weight"})   # (matrices: 16 rows)
+
+
 def case_indices():
     """Index KATs straight from transformers.vision_utils + torch for several grids."""
     from transformers.vision_utils import get_vision_cu_seqlens, get_vision_position_ids, get_vision_window_index
@@ -303,6 +353,9 @@ def case_indices():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "sft":       # only the SFT fixtures (the others are byte-stable: nothing to regenerate)
+        case_sft("sft_tiny_g2", om.cfg_tiny(2), seed=41, n_frames=4, hw=(56, 84), sec=1.0, spans=[(9, True), (5, False), (6, True)])
+        return
     case_indices()
     case_forward("fwd_tiny_g2", om.cfg_tiny(2), seed=11, n_frames=4, hw=(112, 112), sec=1.0, C=9)
     case_forward("fwd_tiny_g2_pad", om.cfg_tiny(2), seed=12, n_frames=2, hw=(84, 140), sec=2.0, C=6, pad_left=5,
@@ -316,6 +369,7 @@ def main():
                         note="(one still image, then a video)")
     case_forward_images("fwd_tiny_g2_img2", om.cfg_tiny(2), seed=32, image_hws=[(140, 84), (56, 56)], video=None, C=5, pad_left=3,
                         note="(two still images, no video, left pad)")
+    case_sft("sft_tiny_g2", om.cfg_tiny(2), seed=41, n_frames=4, hw=(56, 84), sec=1.0, spans=[(9, True), (5, False), (6, True)])
 
 
 if __name__ == "__main__":

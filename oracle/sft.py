@@ -4,7 +4,9 @@ Test infrastructure only (see oracle/__init__.py).
 
 * `sft_loss`: the loss of the mixed-modality forward (/root/reference/train/src/train/monkey_patch_forward.py:619-631): logits to
   fp32, shift so that position t predicts token t + 1, `CrossEntropyLoss()` (mean over the positions whose label is not -100) over
-  the flattened batch.
+  the flattened batch.  PINNED: tests/golden/sft_tiny_g2.npz (oracle/make_golden.py case_sft) holds HF transformers' own loss for
+  `labels` and HF autograd's gradients of six tensors (LM, lm_head, merger, ViT block) on a video row with two supervised spans; this
+  function over oracle forward_logits reproduces the loss exactly and the gradients to 1e-6 (tests/test_sft_cpu.py).
 * `labels_of`: the per-piece label rule of the dataset (/root/reference/train/src/dataset/sft_dataset.py:127-176): system and
   user pieces (up to and including the answer's role header) are -100, the answer piece (`{answer}<|im_end|>\\n`) is supervised.
 * `LoraOracle`: the adapters `get_peft_model(model, LoraConfig(r, lora_alpha, target_modules, lora_dropout, bias="none"))` puts on

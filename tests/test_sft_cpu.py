@@ -2,6 +2,7 @@
 (/root/reference/train/src/dataset/sft_dataset.py:127-176, data_utils.py:16-38) -- the reference's dataset needs the HF processor and
 a tokenizer download, neither present here, so these are restatement checks, not fixture checks."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -172,3 +173,28 @@ def test_sft_row_order_shards_batches_over_ranks_and_resumes():
         assert r0[a][0] == order[0:2] and r1[a][0] == order[2:4] and r0[a][1] == order[4:6]        # batch k -> rank k mod 2
     assert list(make(0, 2, done=3).iter_steps()) == r0[3:]
     assert list(make(0, 1, n=3, bs=2, accum=2, steps=4).iter_steps()) == []                          # fewer rows than one step: nothing to do
+
+
+def test_oracle_sft_loss_and_gradients_reproduce_the_hf_fixture(golden_dir):
+    """tests/golden/sft_tiny_g2.npz (oracle/make_golden.py case_sft): HF transformers' own loss for `labels` and HF autograd's gradients
+    on a video row with two supervised answer spans -- the oracle's forward + oracle.sft.sft_loss + torch autograd must reproduce them.
+    This pins the SFT half of the oracle against the library that holds the reference's arithmetic."""
+    import torch
+    from tests.helpers import pixels_from_frames
+    d = np.load(os.path.join(golden_dir, "sft_tiny_g2.npz"))
+    ocfg = om.cfg_tiny(int(d["group"]))
+    w = om.make_weights(ocfg, seed=int(d["seed"]))
+    px, grid = pixels_from_frames(d["frames_u8"], ocfg.vision)
+    assert tuple(grid) == tuple(d["video_grid_thw"][0])
+    wt = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    ids, labels = torch.from_numpy(d["input_ids"])[None], torch.from_numpy(d["labels"])[None]
+    loss = osft.sft_loss(om.forward_logits(wt, ocfg, ids, None, torch.from_numpy(px), d["video_grid_thw"], [float(d["sec"])]), labels)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(d["hf_loss"])) < 1e-5
+    for key in d.files:
+        if key.startswith("hf_grad:"):
+            name, ref = key[len("hf_grad:"):], torch.from_numpy(d[key])
+            got = wt[name].grad[:16] if ref.dim() == 2 else wt[name].grad
+            assert (got - ref).norm() <= 1e-4 * ref.norm(), name
+    ref = torch.from_numpy(d["hf_lm_head_grad_rows"])
+    assert (wt["lm_head.weight"].grad[:64] - ref).norm() <= 1e-4 * ref.norm()

@@ -105,7 +105,7 @@ def parse():
     p.add_argument("--prompts-per-gpu", type=int, default=None,
                    help="prompt groups per GPU per optimiser step (the reference's per_device_train_batch_size x "
                         "gradient_accumulation_steps); groups are decoded together, P*G <= 256 rows per weight pass (128 with fp8 decode "
-                        "weights).  Default: 22 up to 32 frames (bf16 or fp8 x fp8 decode), else 16; clamped to the row limit (128 for weight-only fp8)")
+                        "weights).  Default: 176 // G up to 32 frames (22 at G = 8; bf16 or fp8 x fp8 decode), else 128 // G; clamped to the row limit (128 for weight-only fp8)")
     p.add_argument("--prompt-pool-gb", type=float, default=9.0,
                    help="HBM for the resident synthetic prompts: distinct prompts for every step while they fit, else a cyclic pool")
     return p.parse_args()
@@ -350,8 +350,8 @@ def main():
     from video_r2_amd.train import Trainer
     upd = None if a.no_update else Trainer(eng, pol, grad_exchange=a.grad_exchange)       # fp32 masters + Adam moments + transposed packed copies
     P = a.prompts_per_gpu
-    if P is None:          # 176 sequences per decode weight pass at the headline workload; the longer-prompt / fp8 configs keep 128
-        P = 22 if (a.decode_weights != "fp8w" and a.frames <= 32) else 16
+    if P is None:          # 176 sequences per decode weight pass up to 32 frames (22 groups of G = 8, 44 of G = 4); 64-frame prompts and
+        P = max(1, 176 // G) if (a.decode_weights != "fp8w" and a.frames <= 32) else max(1, 128 // G)     # weight-only fp8 keep 128
     P = max(1, min(P, (128 if a.decode_weights == "fp8w" else 256) // G))
     # synthetic prompts resident before the timed region: distinct ones for every step while they fit --prompt-pool-gb (19 MB of fp32
     # pixel rows per 32-frame prompt), else a pool of that many steps' worth walked cyclically (every step still runs all of its
